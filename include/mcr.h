@@ -1,0 +1,210 @@
+/*
+ * mcr.h — C ABI of the MI355X-native Monte Carlo retirement path engine.
+ *
+ * This is the drop-in boundary for ONE hot path of rflamino/monte_carlo_retirement:
+ * the per-path loop `RetirementMonteCarloSimulator._run_single_simulation_path`
+ * (reference backend/simulation.py:476-950) and the batch driver above it
+ * (`run_monte_carlo_simulations`, backend/simulation.py:952-1128).  The reference
+ * has no FFI layer of its own (it is pure Python); these entry points are what a
+ * ctypes binding inside the reference's `run_monte_carlo_simulations` would call
+ * (see INTEGRATION.md).  Plain C types only: no torch, no C++ in the signatures.
+ *
+ * Every compute entry point runs hand-written HIP kernels on a gfx950 device.
+ * There is NO CPU fallback in this library: without a usable HIP device every
+ * compute call returns MCR_ERR_NO_DEVICE and sets mcr_last_error().
+ *
+ * All arithmetic on the path is IEEE fp64, as in the reference (Python float).
+ */
+#ifndef MCR_H_
+#define MCR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCR_ABI_VERSION 1
+#define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
+#define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
+#define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */
+
+/* error codes (0 = success); message text via mcr_last_error() */
+#define MCR_OK 0
+#define MCR_ERR_INVALID_ARG (-1)
+#define MCR_ERR_NO_DEVICE (-2)
+#define MCR_ERR_HIP (-3)
+#define MCR_ERR_UNSUPPORTED (-4)
+
+/* Seed streams: replaces SeedSequence(main).spawn(2) (backend/simulation.py:147-151). */
+#define MCR_STREAM_SEARCH 0u
+#define MCR_STREAM_FINAL 1u
+
+/* One `OtherIncomeStreamConfig` (backend/config.py:12-47), raw field values. */
+typedef struct mcr_stream {
+    double monthly_amount_today; /* config.py:18 */
+    double start_at_age;         /* config.py:23 */
+    double tax_rate;             /* config.py:45 */
+    int32_t duration_years;      /* config.py:33; -1 encodes None (paid indefinitely) */
+    int32_t inflation_indexed;   /* config.py:41 (0/1) */
+} mcr_stream;
+
+/*
+ * The scalars of `Config` (backend/config.py:48-126) that the path reads, plus the
+ * lognormal parameters `RetirementMonteCarloSimulator.__init__` derives from them
+ * (backend/simulation.py:156-170, via arithmetic_to_log_params :14-29).
+ */
+typedef struct mcr_params {
+    double initial_balance;                 /* config.py:56 */
+    double monthly_contribution;            /* config.py:57 */
+    double contribution_growth_rate_annual; /* config.py:58 */
+    double monthly_expenses;                /* config.py:59 */
+    double current_age;                     /* config.py:62 */
+    double allocation_inv1_pct;             /* config.py:70 */
+    double inv1_annual_tax_on_gains_rate;   /* config.py:73 */
+    double inv1_realized_gains_tax_rate;    /* config.py:74 */
+    double inv2_annual_tax_on_gains_rate;   /* config.py:79 */
+    double inv2_realized_gains_tax_rate;    /* config.py:80 */
+    double inv1_mu_log, inv1_sigma_log;     /* simulation.py:157-159 */
+    double inf_mu_log, inf_sigma_log;       /* simulation.py:160-162 */
+    double prem_mu_log, prem_sigma_log;     /* simulation.py:163-166 */
+    double equity_inflation_rho;            /* simulation.py:170 */
+    int32_t retirement_years;               /* config.py:68 (> 0) */
+    int32_t inv1_use_realized_gains_tax_system; /* config.py:75 (0/1) */
+    int32_t inv2_use_realized_gains_tax_system; /* config.py:81 (0/1) */
+    int32_t n_streams;                      /* len(other_income_streams) <= MCR_MAX_STREAMS */
+    mcr_stream streams[MCR_MAX_STREAMS];    /* config.py:99, list order preserved */
+} mcr_params;
+
+/* Shapes implied by (params, working_months); simulation.py:487,585-589,902. */
+typedef struct mcr_sizes {
+    int32_t total_months;      /* working_months + retirement_years*12 */
+    int32_t shock_rows;        /* max(total_months, 1)  (simulation.py:488) */
+    int32_t num_working_years; /* ceil(working_months/12) */
+    int32_t trajectory_len;    /* T = 1 + num_working_years + retirement_years */
+    int32_t retirement_years;  /* rows of the withdrawal-rate trajectory */
+    int32_t ruin_bins;         /* retirement_years + 2, see mcr_outputs.ruin_year_bins */
+} mcr_sizes;
+
+/* indices into mcr_outputs.counters */
+#define MCR_CTR_SUCCESS 0 /* number of paths with Success == True */
+#define MCR_CTR_PATHS 1   /* number of paths simulated */
+#define MCR_N_COUNTERS 2
+
+/*
+ * Output buffers of one batch.  Any pointer may be NULL = "not requested"; the kernel
+ * variant is chosen from what is requested (success-count only / + per-path summary /
+ * + yearly trajectories).  Layout is struct-of-arrays; trajectories are TIME-MAJOR
+ * (`row[t*path_stride + i]` for local path i) so that one wavefront store is 512
+ * contiguous bytes.  Field meanings follow the dict returned by
+ * _run_single_simulation_path (simulation.py:939-950).
+ *
+ * For mcr_run_batch the pointers are DEVICE pointers; for mcr_run_batch_host they are
+ * HOST pointers.  Counters / bins are ACCUMULATED into (the caller zeroes them), so
+ * several launches (or several GPUs before an all-reduce) can share one vector.
+ */
+typedef struct mcr_outputs {
+    double* start_balance;                    /* [n] "Start Balance" */
+    double* final_balance;                    /* [n] "Final Balance" = max(0, .) */
+    double* years_to_ruin;                    /* [n] "YearsToRuin" (NaN if success) */
+    double* first_year_gross_withdrawal;      /* [n] */
+    double* first_year_real_gross_withdrawal; /* [n] */
+    double* inflation_at_retirement;          /* [n] */
+    uint8_t* success;                         /* [n] "Success" (0/1) */
+    double* trajectory;                       /* [T][path_stride]  "Trajectory" */
+    double* real_trajectory;                  /* [T][path_stride]  "RealTrajectory" */
+    double* withdrawal_rate_trajectory;       /* [ry][path_stride] NaN-padded */
+    int64_t path_stride;                      /* >= n_paths (elements) */
+    uint64_t* counters;                       /* [MCR_N_COUNTERS] */
+    uint64_t* wr_obs_counts;                  /* [ry]   wr_df.count(axis=1), simulation.py:1111-1113 */
+    uint64_t* ruin_year_bins;                 /* [ry+2] [0]=pre-retirement tax failure (YearsToRuin 0.0,
+                                                 simulation.py:628-629); [1+y]=failed in retirement year y;
+                                                 [ry+1]=failed at the terminal tax settlement (:894-896) */
+} mcr_outputs;
+
+/* ---- library / device ------------------------------------------------------------ */
+int mcr_abi_version(void);
+/* Number of usable HIP devices (0 if none; never fails). */
+int mcr_device_count(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* mcr_last_error(void);
+
+/* ---- host-side derivations (no device needed) -------------------------------------- */
+/* Shapes for (params, working_months).  Returns MCR_ERR_INVALID_ARG for working_months<0,
+ * retirement_years<=0, n_streams out of range. */
+int mcr_query_sizes(const mcr_params* p, int32_t working_months, mcr_sizes* out);
+/* stream_payment_start_month_index (simulation.py:47-63). */
+int32_t mcr_stream_start_month_index(double current_age, int32_t working_months, double start_at_age);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/*
+ * Simulate global paths [path_begin, path_begin+n_paths) for `working_months`, replacing
+ * the loop over _path_seeds in run_monte_carlo_simulations (simulation.py:987-990) with one
+ * kernel launch (one path per lane).  Shocks: Philox4x32-10 keyed by (seed), counter
+ * (path_lo, path_hi, month, stream_id) -> Box-Muller -> rho-mix (replaces _draw_shock_path,
+ * simulation.py:452-466).  Row k depends only on (seed, stream, path, k): common random
+ * numbers across working-month candidates and across any sharding of the path range.
+ *
+ * injected_shocks (optional, device pointer, may be NULL): [n_paths][shock_rows][3] doubles
+ * (equity, inflation, premium) used INSTEAD of the RNG — the parity hook that mirrors
+ * assigning `sim._draw_shock_path` in the reference.
+ *
+ * out: device pointers.  hip_stream: a hipStream_t (NULL = default stream).  The call is
+ * asynchronous: it enqueues on hip_stream and returns.  device: HIP device ordinal.
+ */
+int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id,
+                  uint64_t path_begin, uint64_t n_paths, int32_t working_months,
+                  const double* injected_shocks, const mcr_outputs* out,
+                  int device, void* hip_stream);
+
+/* Same, with HOST buffers in `out` / `injected_shocks`: allocates device scratch, runs,
+ * copies back, synchronises.  Convenience for small batches and non-torch callers. */
+int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id,
+                       uint64_t path_begin, uint64_t n_paths, int32_t working_months,
+                       const double* injected_shocks, const mcr_outputs* out, int device);
+
+/* _draw_shock_path (simulation.py:452-466) for n_paths paths: host out [n_paths][n_months][3]. */
+int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
+                         uint64_t n_paths, int32_t n_months, double rho, double* out,
+                         int device);
+
+/* ---- device unit functions (the scalar helpers the reference's tests call directly) ---- */
+#define MCR_HELPER_WITHDRAW 0      /* _calculate_withdrawal_and_update :201-254; in[5]=(bal,cb,net_target,use_real,rate) out[4]=(bal,cb,gross,net) */
+#define MCR_HELPER_NLV 1           /* _net_liquidation_value :256-272;           in[4]=(bal,cb,use_real,rate) out[1] */
+#define MCR_HELPER_REBALANCE 2     /* _rebalance_portfolio :274-359;             in[4]=(b1,cb1,b2,cb2) out[4] */
+#define MCR_HELPER_ANNUAL_TAX 3    /* _apply_annual_gain_taxes :361-450;         in[6]=(b1,cb1,b2,cb2,g1,g2) out[5]=(b1,cb1,b2,cb2,tax_failed) */
+#define MCR_HELPER_MONTHLY_GROSS 4 /* _monthly_gross_from_shock :468-474;        in[3]=(mu_log,sigma_log,z) out[1] */
+/* Evaluates helper `which` ON THE DEVICE for n rows (host buffers, row-major). */
+int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out,
+                         int64_t n, int device);
+
+/* ---- device-side aggregation (replaces the pandas block, simulation.py:1045-1118) ---- */
+/*
+ * Row-wise quantiles with pandas' semantics (linear interpolation between order statistics,
+ * NaNs skipped): for each of n_rows rows of `n` doubles at rows[r*row_stride + i], writes
+ * out[r*n_q + j] = quantile(q[j]) (NaN for an all-NaN row) and, if counts != NULL,
+ * counts[r] = number of non-NaN entries.  rows/out/counts are DEVICE pointers; q is HOST.
+ * scratch: device buffer of mcr_row_quantiles_scratch_bytes(n_rows, n_q) bytes.
+ */
+int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q);
+int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n,
+                      const double* q, int32_t n_q, double* out, uint64_t* counts,
+                      void* scratch, int device, void* hip_stream);
+
+/*
+ * Histogram of final balances over the successful cohort (the CLI's 100-bin chart,
+ * backend/plotting.py:53-59, np.histogram semantics: n_bins equal-width bins over
+ * [lo, hi], last bin closed).  values/success: DEVICE [n].  minmax: DEVICE [2] doubles;
+ * if use_given_range == 0 the kernel first reduces min/max of the cohort into it.
+ * bins: DEVICE [n_bins] uint64, accumulated into (caller zeroes).
+ */
+int mcr_minmax_success(const double* values, const uint8_t* success, int64_t n,
+                       double* minmax, int device, void* hip_stream);
+int mcr_histogram_success(const double* values, const uint8_t* success, int64_t n,
+                          const double* minmax, int32_t n_bins, uint64_t* bins,
+                          int device, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCR_H_ */

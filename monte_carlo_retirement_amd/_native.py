@@ -1,0 +1,229 @@
+"""ctypes binding of the C ABI declared in include/mcr.h (``csrc/libmcr_hip.so``).
+
+This is the only door into the HIP kernels.  There is no CPU fallback: if the shared
+library is missing, or no HIP device is usable, the compute entry points raise
+``RuntimeError`` — loudly, by design.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+MCR_ABI_VERSION = 1
+MCR_MAX_STREAMS = 16
+MCR_N_COUNTERS = 2
+MCR_CTR_SUCCESS = 0
+MCR_CTR_PATHS = 1
+MCR_STREAM_SEARCH = 0
+MCR_STREAM_FINAL = 1
+
+MCR_HELPER_WITHDRAW = 0
+MCR_HELPER_NLV = 1
+MCR_HELPER_REBALANCE = 2
+MCR_HELPER_ANNUAL_TAX = 3
+MCR_HELPER_MONTHLY_GROSS = 4
+_HELPER_ARITY = {  # which -> (n_in, n_out)
+    MCR_HELPER_WITHDRAW: (5, 4),
+    MCR_HELPER_NLV: (4, 1),
+    MCR_HELPER_REBALANCE: (4, 4),
+    MCR_HELPER_ANNUAL_TAX: (6, 5),
+    MCR_HELPER_MONTHLY_GROSS: (3, 1),
+}
+
+
+class McrStream(C.Structure):
+    _fields_ = [
+        ("monthly_amount_today", C.c_double),
+        ("start_at_age", C.c_double),
+        ("tax_rate", C.c_double),
+        ("duration_years", C.c_int32),
+        ("inflation_indexed", C.c_int32),
+    ]
+
+
+class McrParams(C.Structure):
+    _fields_ = [
+        ("initial_balance", C.c_double),
+        ("monthly_contribution", C.c_double),
+        ("contribution_growth_rate_annual", C.c_double),
+        ("monthly_expenses", C.c_double),
+        ("current_age", C.c_double),
+        ("allocation_inv1_pct", C.c_double),
+        ("inv1_annual_tax_on_gains_rate", C.c_double),
+        ("inv1_realized_gains_tax_rate", C.c_double),
+        ("inv2_annual_tax_on_gains_rate", C.c_double),
+        ("inv2_realized_gains_tax_rate", C.c_double),
+        ("inv1_mu_log", C.c_double),
+        ("inv1_sigma_log", C.c_double),
+        ("inf_mu_log", C.c_double),
+        ("inf_sigma_log", C.c_double),
+        ("prem_mu_log", C.c_double),
+        ("prem_sigma_log", C.c_double),
+        ("equity_inflation_rho", C.c_double),
+        ("retirement_years", C.c_int32),
+        ("inv1_use_realized_gains_tax_system", C.c_int32),
+        ("inv2_use_realized_gains_tax_system", C.c_int32),
+        ("n_streams", C.c_int32),
+        ("streams", McrStream * MCR_MAX_STREAMS),
+    ]
+
+
+class McrSizes(C.Structure):
+    _fields_ = [
+        ("total_months", C.c_int32),
+        ("shock_rows", C.c_int32),
+        ("num_working_years", C.c_int32),
+        ("trajectory_len", C.c_int32),
+        ("retirement_years", C.c_int32),
+        ("ruin_bins", C.c_int32),
+    ]
+
+
+class McrOutputs(C.Structure):
+    """Pointers are plain addresses (device or host, depending on the entry point)."""
+
+    _fields_ = [
+        ("start_balance", C.c_void_p),
+        ("final_balance", C.c_void_p),
+        ("years_to_ruin", C.c_void_p),
+        ("first_year_gross_withdrawal", C.c_void_p),
+        ("first_year_real_gross_withdrawal", C.c_void_p),
+        ("inflation_at_retirement", C.c_void_p),
+        ("success", C.c_void_p),
+        ("trajectory", C.c_void_p),
+        ("real_trajectory", C.c_void_p),
+        ("withdrawal_rate_trajectory", C.c_void_p),
+        ("path_stride", C.c_int64),
+        ("counters", C.c_void_p),
+        ("wr_obs_counts", C.c_void_p),
+        ("ruin_year_bins", C.c_void_p),
+    ]
+
+
+#: The symbols include/mcr.h declares; tests check that the built library exports them all.
+ABI_SYMBOLS = (
+    "mcr_abi_version",
+    "mcr_device_count",
+    "mcr_last_error",
+    "mcr_query_sizes",
+    "mcr_stream_start_month_index",
+    "mcr_run_batch",
+    "mcr_run_batch_host",
+    "mcr_draw_shocks_host",
+    "mcr_eval_helper_host",
+    "mcr_row_quantiles_scratch_bytes",
+    "mcr_row_quantiles",
+    "mcr_minmax_success",
+    "mcr_histogram_success",
+)
+
+_LIB_NAME = "libmcr_hip.so"
+_lib: Optional[C.CDLL] = None
+_lib_lock = threading.Lock()
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
+
+
+def _declare(lib: C.CDLL) -> None:
+    P = C.POINTER
+    lib.mcr_abi_version.restype = C.c_int
+    lib.mcr_abi_version.argtypes = []
+    lib.mcr_device_count.restype = C.c_int
+    lib.mcr_device_count.argtypes = []
+    lib.mcr_last_error.restype = C.c_char_p
+    lib.mcr_last_error.argtypes = []
+    lib.mcr_query_sizes.restype = C.c_int
+    lib.mcr_query_sizes.argtypes = [P(McrParams), C.c_int32, P(McrSizes)]
+    lib.mcr_stream_start_month_index.restype = C.c_int32
+    lib.mcr_stream_start_month_index.argtypes = [C.c_double, C.c_int32, C.c_double]
+    lib.mcr_run_batch.restype = C.c_int
+    lib.mcr_run_batch.argtypes = [
+        P(McrParams), C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
+        C.c_void_p, P(McrOutputs), C.c_int, C.c_void_p,
+    ]
+    lib.mcr_run_batch_host.restype = C.c_int
+    lib.mcr_run_batch_host.argtypes = [
+        P(McrParams), C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
+        C.c_void_p, P(McrOutputs), C.c_int,
+    ]
+    lib.mcr_draw_shocks_host.restype = C.c_int
+    lib.mcr_draw_shocks_host.argtypes = [
+        C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_double,
+        C.c_void_p, C.c_int,
+    ]
+    lib.mcr_eval_helper_host.restype = C.c_int
+    lib.mcr_eval_helper_host.argtypes = [
+        C.c_int, P(McrParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+    ]
+    lib.mcr_row_quantiles_scratch_bytes.restype = C.c_int64
+    lib.mcr_row_quantiles_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.mcr_row_quantiles.restype = C.c_int
+    lib.mcr_row_quantiles.argtypes = [
+        C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+    ]
+    lib.mcr_minmax_success.restype = C.c_int
+    lib.mcr_minmax_success.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+    ]
+    lib.mcr_histogram_success.restype = C.c_int
+    lib.mcr_histogram_success.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
+        C.c_int, C.c_void_p,
+    ]
+
+
+def load_library() -> C.CDLL:
+    """Load (once) and return the HIP engine.  Raises RuntimeError if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            path = library_path()
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    f"HIP engine not built: {path} is missing. Run "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(there is no CPU fallback)."
+                )
+            try:
+                lib = C.CDLL(path)
+            except OSError as exc:
+                raise RuntimeError(f"cannot load HIP engine {path}: {exc}") from exc
+            _declare(lib)
+            if lib.mcr_abi_version() != MCR_ABI_VERSION:
+                raise RuntimeError(
+                    f"{path}: ABI version {lib.mcr_abi_version()} != {MCR_ABI_VERSION}; rebuild"
+                )
+            _lib = lib
+        return _lib
+
+
+def last_error() -> str:
+    msg = load_library().mcr_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def device_count() -> int:
+    return int(load_library().mcr_device_count())
+
+
+def require_device() -> None:
+    if device_count() <= 0:
+        raise RuntimeError(
+            "no usable HIP device: the Monte Carlo path engine runs only on a gfx950 GPU "
+            "(there is no CPU fallback)"
+        )
+
+
+def helper_arity(which: int):
+    return _HELPER_ARITY[which]

@@ -1,0 +1,2 @@
+"""CPU oracle — TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package."""
