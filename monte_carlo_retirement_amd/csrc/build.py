@@ -1,0 +1,51 @@
+"""Builds csrc/libmcr_hip.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m monte_carlo_retirement_amd.csrc.build [--force] [--verbose]
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["mcr_hip.hip", "mcr_aggregate.hip"]
+HEADERS = ["mcr_device.h", "mcr_host.h", os.path.join("..", "..", "include", "mcr.h")]
+TARGET = os.path.join(HERE, "libmcr_hip.so")
+ARCH = "gfx950"
+# -ffp-contract=off: every a*b+c rounds twice, like the reference's Python floats.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"--offload-arch={ARCH}",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(TARGET):
+        return True
+    t = os.path.getmtime(TARGET)
+    deps = [os.path.join(HERE, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not is_stale():
+        return TARGET
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-o", TARGET] + [os.path.join(HERE, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TARGET
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--verbose" in sys.argv else [])
+    print(TARGET)

@@ -1,0 +1,209 @@
+// mcr_device.h — device-side building blocks of the Monte Carlo retirement path kernel (gfx950).
+//
+// One simulated path lives in ONE LANE: the monthly state (two balances, two cost bases, two
+// gain accumulators, the price level, the contribution) stays in VGPRs for the whole horizon;
+// scenario parameters are wave-uniform kernel arguments (SGPRs).  All arithmetic is IEEE fp64
+// and the translation unit is compiled with -ffp-contract=off so every a*b+c rounds twice, as
+// in the reference (CPython floats).  Each function cites the reference lines it replaces
+// (rflamino/monte_carlo_retirement, backend/simulation.py).
+//
+// Data-dependent branches of the reference (sell inv1 / sell inv2, early-outs) are written
+// branch-free with selected operands: the lanes of a wavefront diverge on them almost every
+// month, so both sides would otherwise be executed under exec masks.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcr.h"
+
+namespace mcr {
+
+constexpr double kEps = MCR_SMALL_EPSILON;
+constexpr int kMPY = MCR_MONTHS_PER_YEAR;
+constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
+
+// Per-stream data prepared on the host (mcr_abi: derive_params) from mcr_stream.
+struct DevStream {
+    double amount;        // monthly_amount_today
+    double keep;          // 1.0 - tax_rate                      (simulation.py:675-677)
+    int32_t start_month;  // stream_payment_start_month_index    (:47-63, :603-608)
+    int32_t end_month;    // start + duration_years*12, INT32_MAX for None (:609-613, :653-656)
+    int32_t indexed;      // inflation_indexed
+    int32_t lock_slot;    // LDS column of the frozen nominal amount (non-indexed streams), else -1
+};
+
+// Wave-uniform scenario block (kernel argument -> SGPRs).
+struct DevParams {
+    double initial_balance, monthly_contribution, contrib_growth_factor /* 1 + g */, monthly_expenses;
+    double alloc1, alloc2;             // allocation_inv1_pct, 1.0 - allocation_inv1_pct (config.py:124-126)
+    double real_rate1, real_rate2;     // realized-gains rate if the asset uses that system, else 0.0
+    double annual_rate1, annual_rate2; // annual-gains rate if the asset does NOT use the realized system, else 0.0
+    double a1, b1;                     // inv1:      mu_log/12, sigma_log/sqrt(12)   (:473)
+    double ainf, binf;                 // inflation: idem
+    double aprem, bprem;               // inv2 premium over inflation: idem
+    double rho, rho_c;                 // rho, sqrt(max(0, 1 - rho^2))               (:460-464)
+    int32_t working_months, retirement_years, total_months, shock_rows;
+    int32_t num_working_years, trajectory_len, n_streams, n_lock_slots;
+    int32_t contrib_grows;             // contribution_growth_rate_annual > 0        (:516)
+    int32_t any_annual_tax;            // annual_rate1 > 0 || annual_rate2 > 0
+    DevStream streams[MCR_MAX_STREAMS];
+};
+
+// ---------------------------------------------------------------------------------------------
+// RNG: Philox4x32-10 (Salmon et al. SC'11, Random123 constants).  Counter = (path_lo, path_hi,
+// month, stream_id), key = (seed_lo, seed_hi).  The key schedule is wave-uniform (scalar ALU).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One shock row (equity, inflation, premium); replaces row `month` of _draw_shock_path (:452-466).
+//   u = (x + 0.5) * 2^-32 in (0,1);  (z0, z1) = sqrt(-2 ln u0) (cos, sin)(2 pi u1);
+//   z2 = sqrt(-2 ln u2) cos(2 pi u3);  equity = z0, inflation = rho z0 + rho_c z1, premium = z2.
+__device__ __forceinline__ void shock_row(uint64_t seed, uint32_t stream_id, uint64_t path,
+                                          uint32_t month, double rho, double rho_c, double& z_eq,
+                                          double& z_inf, double& z_prem) {
+    uint32_t x[4];
+    philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), month, stream_id, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), x);
+    constexpr double S = 2.3283064365386962890625e-10;  // 2^-32
+    const double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
+    const double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;
+    const double r0 = sqrt(-2.0 * log(u0));
+    const double r1 = sqrt(-2.0 * log(u2));
+    double s, c;
+    sincospi(2.0 * u1, &s, &c);
+    const double z0 = r0 * c, z1 = r0 * s;
+    z_eq = z0;
+    z_inf = rho * z0 + rho_c * z1;
+    z_prem = r1 * cospi(2.0 * u3);
+}
+
+// _monthly_gross_from_shock (:468-474) with a = mu_log/12 and b = sigma_log/sqrt(12) precomputed.
+__device__ __forceinline__ double monthly_gross(double a, double b, double z) { return exp(a + b * z); }
+
+// _net_liquidation_value (:256-272); rate = realized rate if that system applies else 0.0.
+__device__ __forceinline__ double net_liquidation_value(double bal, double cb, double rate) {
+    const double tax = fmax(0.0, bal - cb) * rate;
+    const double v = fmax(0.0, bal - tax);
+    return bal <= kEps ? 0.0 : v;
+}
+
+// _calculate_withdrawal_and_update (:201-254), branch-free.
+__device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
+                                         double& gross_out, double& net_out) {
+    const bool skip = (bal <= kEps) || (net_target <= 0.0);              // :218
+    const double gain_fraction = fmax(0.0, bal - cb) / bal;              // :221
+    const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
+    const double gross = fmin(net_target / net_fraction, bal);           // :228-231
+    const double fraction_sold = fmin(1.0, gross / bal);                 // :233
+    const double basis_removed = fmin(cb, cb * fraction_sold);           // :234
+    const double taxable_gain = fmax(0.0, gross - basis_removed);        // :235
+    const double tax_paid = taxable_gain * rate;                         // :236-240
+    const double net_cash = fmax(0.0, gross - tax_paid);                 // :241
+    double nb = fmax(0.0, bal - gross);                                  // :243
+    double ncb = fmax(0.0, cb - basis_removed);                          // :244
+    const bool dust = nb <= kEps;                                        // :245-247
+    nb = dust ? 0.0 : nb;
+    ncb = dust ? 0.0 : ncb;
+    bal = skip ? fmax(0.0, bal) : nb;                                    // :219
+    cb = skip ? fmax(0.0, cb) : ncb;
+    gross_out = skip ? 0.0 : gross;
+    net_out = skip ? 0.0 : net_cash;
+}
+
+// _rebalance_portfolio (:274-359), branch-free: the over-weight asset is the seller.
+__device__ __forceinline__ void rebalance(const DevParams& P, double& b1, double& c1, double& b2,
+                                          double& c2) {
+    const double total = b1 + b2;                                  // :288
+    const double drift1 = b1 - total * P.alloc1;                   // :293-294
+    const bool act = (total > kEps) && (fabs(drift1) > kEps);      // :290-296
+    const bool sell1 = drift1 > 0.0;                               // :298
+    const double drift2 = b2 - total * P.alloc2;                   // :328
+    const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;       // seller
+    const double bb = sell1 ? b2 : b1, cbuy = sell1 ? c2 : c1;     // buyer
+    const double drift = sell1 ? drift1 : drift2;
+    const double alloc_s = sell1 ? P.alloc1 : P.alloc2;            // the SOLD asset's own weight (:309,:337)
+    const double rate_s = sell1 ? P.real_rate1 : P.real_rate2;
+    const double gain_fraction = fmax(0.0, bs - cs) / bs;          // :301 / :329
+    const double tax_per_dollar = gain_fraction * rate_s;          // :302-306
+    const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
+    const double gross_sale = fmin(bs, drift / denom);             // :311
+    const double fraction_sold = gross_sale / bs;                  // :312
+    const double basis_removed = fmin(cs, cs * fraction_sold);     // :313
+    const double taxable_gain = fmax(0.0, gross_sale - basis_removed);  // :314
+    const double tax_paid = taxable_gain * rate_s;                 // :315-319
+    const double net_purchase = gross_sale - tax_paid;             // :320
+    double nbs = fmax(0.0, bs - gross_sale);                       // :322
+    double ncs = fmax(0.0, cs - basis_removed);                    // :323
+    double nbb = bb + net_purchase;                                // :324
+    double ncb = cbuy + net_purchase;                              // :325
+    const bool dust_s = nbs <= kEps, dust_b = nbb <= kEps;         // :355-358
+    nbs = dust_s ? 0.0 : nbs;
+    ncs = dust_s ? 0.0 : ncs;
+    nbb = dust_b ? 0.0 : nbb;
+    ncb = dust_b ? 0.0 : ncb;
+    const double r1 = sell1 ? nbs : nbb, rc1 = sell1 ? ncs : ncb;
+    const double r2 = sell1 ? nbb : nbs, rc2 = sell1 ? ncb : ncs;
+    b1 = act ? r1 : b1;
+    c1 = act ? rc1 : c1;
+    b2 = act ? r2 : b2;
+    c2 = act ? rc2 : c2;
+}
+
+// _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
+__device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, double& b1, double& c1,
+                                                  double& b2, double& c2, double gain1, double gain2) {
+    bool tax_failed = false;
+    if (P.any_annual_tax) {  // wave-uniform: with no annual-tax asset the bill is 0 (:380-390)
+        const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
+        const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
+        const double total_due = due1 + due2;                         // :390
+        const double cap1 = net_liquidation_value(b1, c1, P.real_rate1);  // :392-397
+        const double cap2 = net_liquidation_value(b2, c2, P.real_rate2);  // :398-403
+        const double cap = cap1 + cap2;                               // :404
+        const double pay = fmin(total_due, cap);                      // :405
+        tax_failed = pay < total_due - kEps;                          // :406
+        if (cap > kEps && pay > 0.0) {                                // :408
+            const double share1 = cap1 / cap;                         // :409
+            const double share2 = 1.0 - share1;                       // :410
+            double g, net1, net2;
+            withdraw(b1, c1, pay * share1, P.real_rate1, g, net1);    // :411-419
+            withdraw(b2, c2, pay * share2, P.real_rate2, g, net2);    // :420-428
+            tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
+        }
+    }
+    rebalance(P, b1, c1, b2, c2);  // :432-442 (always)
+    return tax_failed;
+}
+
+// Market step shared by both phases (:522-538 and :695-714).
+__device__ __forceinline__ void market_step(const DevParams& P, double z_eq, double z_inf,
+                                            double z_prem, double& b1, double& b2, double& gacc1,
+                                            double& gacc2, double& infl) {
+    const double g1 = monthly_gross(P.a1, P.b1, z_eq);
+    const double ginf = monthly_gross(P.ainf, P.binf, z_inf);
+    const double gprem = monthly_gross(P.aprem, P.bprem, z_prem);
+    const double g2 = ginf * gprem;   // :532
+    gacc1 += b1 * (g1 - 1.0);         // :534
+    gacc2 += b2 * (g2 - 1.0);         // :535
+    b1 *= g1;                         // :536
+    b2 *= g2;                         // :537
+    infl *= ginf;                     // :538
+}
+
+}  // namespace mcr

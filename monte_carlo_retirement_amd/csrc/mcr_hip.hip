@@ -1,0 +1,644 @@
+// mcr_hip.hip — kernels + C ABI (include/mcr.h) of the MI355X Monte Carlo retirement engine.
+//
+// K1  path_kernel<MODE>   one path per lane; the whole horizon in registers
+//       MODE 0: success count only          (no per-path HBM traffic; BASELINE config 2)
+//       MODE 1: + per-path summary fields   (SoA, 49 B/path)
+//       MODE 2: + yearly trajectories       (time-major [T][N]: 512 contiguous bytes per wave store)
+//     reductions: wave ballot+popcount -> LDS -> one global atomic per workgroup.
+// Helpers: helper_kernel (device unit functions), shocks_kernel (_draw_shock_path).
+// Aggregation kernels (quantiles / histogram) live in mcr_aggregate.hip.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/build.py).  gfx950 only.
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "mcr_device.h"
+#include "mcr_host.h"
+
+namespace mcr {
+
+// ---------------------------------------------------------------------------------------------
+// K1: the per-path state machine (_run_single_simulation_path, simulation.py:476-950)
+// ---------------------------------------------------------------------------------------------
+struct KernelIO {
+    uint64_t seed;
+    uint64_t path_begin;
+    uint64_t n_paths;
+    const double* injected;  // [n_paths][shock_rows][3] or nullptr
+    mcr_outputs out;
+    uint32_t stream_id;
+};
+
+__device__ __forceinline__ double nan_f64() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const KernelIO io) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    // LDS: [n_lock_slots][kBlock] doubles (frozen nominal stream amounts), then block counters
+    double* lock_lds = reinterpret_cast<double*>(smem_raw);
+    unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
+    // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram
+    const int ry = P.retirement_years;
+    const int n_blk = 1 + (ry + 2) + (ry + 1);
+    for (int k = threadIdx.x; k < n_blk; k += kBlock) blk[k] = 0u;
+    __syncthreads();
+
+    const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = local < io.n_paths;
+    const uint64_t li = valid ? local : (io.n_paths - 1);  // tail lanes shadow the last path, write nothing
+    const uint64_t path = io.path_begin + li;
+    const int64_t stride = io.out.path_stride;
+    const double* inj = io.injected ? io.injected + (size_t)li * 3u * (size_t)P.shock_rows : nullptr;
+
+    constexpr bool kSummary = MODE >= 1;
+    constexpr bool kTraj = MODE >= 2;
+    double* traj = kTraj ? io.out.trajectory : nullptr;
+    double* rtraj = kTraj ? io.out.real_trajectory : nullptr;
+    double* wrt = kTraj ? io.out.withdrawal_rate_trajectory : nullptr;
+
+    auto put_sample = [&](int t, double nominal, double px) {  // :574-576, :928-931
+        if (kTraj && valid) {
+            if (traj) traj[(int64_t)t * stride + (int64_t)li] = nominal;
+            if (rtraj) rtraj[(int64_t)t * stride + (int64_t)li] = px > kEps ? nominal / px : 0.0;
+        }
+    };
+    auto shocks = [&](int row, double& ze, double& zi, double& zp) {
+        if (inj) {
+            const int r = row < P.shock_rows - 1 ? row : P.shock_rows - 1;  // :692
+            ze = inj[3 * r + 0]; zi = inj[3 * r + 1]; zp = inj[3 * r + 2];
+        } else {
+            shock_row(io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, ze, zi, zp);
+        }
+    };
+
+    // ---- initial state (:490-510) ----
+    double b1 = P.initial_balance * P.alloc1;  // :499
+    double b2 = P.initial_balance - b1;        // :500
+    double c1 = b1, c2 = b2;                   // :501-502
+    double contrib = P.monthly_contribution;   // :504
+    double gacc1 = 0.0, gacc2 = 0.0;           // :505-506
+    double infl = 1.0;                         // :508
+    bool pre_fail = false;                     // :510
+    int t_idx = 0;
+    put_sample(t_idx++, P.initial_balance, 1.0);  // :490-492
+
+    // ---- accumulation (:513-579): no lane leaves this loop early ----
+    const int wm = P.working_months;
+    for (int m = 1; m <= wm; ++m) {
+        if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) contrib *= P.contrib_growth_factor;  // :514-517
+        double ze, zi, zp;
+        shocks(m - 1, ze, zi, zp);                                     // :519-520
+        market_step(P, ze, zi, zp, b1, b2, gacc1, gacc2, infl);        // :522-538
+        const double k1 = contrib * P.alloc1;                          // :540-542
+        const double k2 = contrib - k1;                                // :543
+        b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
+        rebalance(P, b1, c1, b2, c2);                                  // :549-553
+        if (m % kMPY == 0) {                                           // :557
+            pre_fail |= annual_gain_taxes(P, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            put_sample(t_idx++, b1 + b2, infl);                        // :574-576
+            gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
+        }
+    }
+    const double start_balance = b1 + b2;  // :581
+    const double infl_ret = infl;          // :582
+    if (wm > 0 && wm % kMPY != 0) put_sample(t_idx++, start_balance, infl_ret);  // :590-594
+
+    // ---- decumulation (:632-868) ----
+    double fy_gross = 0.0, fy_real = 0.0;            // :623-624
+    bool alive = !pre_fail;                          // :627, :633
+    bool succeeded = !pre_fail;
+    double years_to_ruin = pre_fail ? 0.0 : nan_f64();  // :497, :628-629
+    int ruin_bin = pre_fail ? 0 : -1;
+    int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
+    int year = 0;
+    for (; year < ry; ++year) {
+        if (__ballot(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
+        double tg1 = 0.0, tg2 = 0.0, treal = 0.0;  // :635-637
+        bool yfail = false;                        // :638
+        int fail_rmi = 0;
+        for (int mi = 0; mi < kMPY; ++mi) {
+            const int rmi = year * kMPY + mi;  // :641-643
+            if (alive && !yfail) {
+                const double price = infl;                             // :644
+                const double expenses = P.monthly_expenses * price;    // :645-647
+                double income = 0.0;                                   // :649
+                for (int s = 0; s < P.n_streams; ++s) {                // :650 (wave-uniform)
+                    const DevStream& S = P.streams[s];
+                    if (rmi < S.start_month || rmi >= S.end_month) continue;  // :653-658
+                    double nominal;
+                    if (S.indexed) {
+                        nominal = S.amount * price;                    // :661-665
+                    } else {
+                        double* slot = lock_lds + (size_t)S.lock_slot * kBlock + threadIdx.x;
+                        if (rmi == S.start_month) *slot = S.amount * price;  // :667-671 (first active month)
+                        nominal = *slot;                               // :672-674
+                    }
+                    income += nominal * S.keep;                        // :675-677
+                }
+                const double need = fmax(0.0, expenses - income);      // :679-682
+                bool stop = false;
+                if (b1 + b2 <= kEps && need > kEps) {                  // :684-690 (FAIL-1, no shock consumed)
+                    yfail = true; stop = true;
+                }
+                if (!stop) {
+                    double ze, zi, zp;
+                    shocks(wm + rmi, ze, zi, zp);                      // :692-693
+                    market_step(P, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
+                    if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
+                        b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
+                        yfail = true; stop = true;
+                    }
+                }
+                if (!stop) {
+                    const double cap1 = net_liquidation_value(b1, c1, P.real_rate1);  // :726-731
+                    const double cap2 = net_liquidation_value(b2, c2, P.real_rate2);  // :732-737
+                    const double cap = cap1 + cap2;                                   // :738
+                    const double target = fmax(0.0, fmin(need, cap));                 // :739-742
+                    if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
+                    const double prop1 = cap > kEps ? cap1 / cap : P.alloc1;          // :750-754
+                    const double prop2 = 1.0 - prop1;                                 // :755
+                    double gw1, nw1, gw2, nw2;
+                    withdraw(b1, c1, target * prop1, P.real_rate1, gw1, nw1);         // :757-765
+                    tg1 += gw1;                                                       // :766
+                    withdraw(b2, c2, target * prop2, P.real_rate2, gw2, nw2);         // :768-776
+                    tg2 += gw2;                                                       // :777
+                    if (kSummary) treal += (gw1 + gw2) * infl_ret / fmax(price, kEps);  // :778-782
+                    if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
+                    rebalance(P, b1, c1, b2, c2);                                     // :792-796
+                    if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
+                        const bool tf = annual_gain_taxes(P, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
+                        yfail = yfail || tf;                                          // :821-822
+                    }
+                }
+                if (yfail) fail_rmi = rmi;  // :825-828, :844-847
+            }
+        }
+        // ---- year end (:830-868); lanes that were already dead pad with 0 / NaN (:902-916,:934-935) ----
+        double sample = 0.0, wr = nan_f64();
+        if (alive) {
+            const double ygw = tg1 + tg2;                                              // :830-832
+            const double wr_pct = start_balance > kEps ? (treal / start_balance) * 100.0 : 0.0;  // :834-840
+            if (year == 0) { fy_gross = ygw; fy_real = treal; }                        // :852-856, :861-865
+            if (yfail) {
+                succeeded = false;                                                     // :843
+                years_to_ruin = (double)(fail_rmi + 1) / (double)kMPY;                 // :825-827, :844-847
+                ruin_bin = 1 + year;
+                sample = fmax(0.0, b1 + b2);                                           // :848
+                alive = false;                                                         // :857
+            } else {
+                wr = wr_pct;                                                           // :859
+                sample = b1 + b2;                                                      // :867
+                done_years = year + 1;
+            }
+        }
+        put_sample(t_idx, sample, infl);  // dead lanes: 0 / px = 0 (:906-916, :928-931)
+        ++t_idx;
+        if (kTraj && valid && wrt) wrt[(int64_t)year * stride + (int64_t)li] = wr;  // :851, :859, :934-935
+    }
+    for (; year < ry; ++year) {  // the whole wave failed early: pad (:902-916, :934-935)
+        put_sample(t_idx++, 0.0, infl);
+        if (kTraj && valid && wrt) wrt[(int64_t)year * stride + (int64_t)li] = nan_f64();
+    }
+
+    // ---- terminal partial tax period (:873-898) ----
+    if (P.total_months % kMPY != 0) {  // wave-uniform
+        if (succeeded) {
+            const bool tf = annual_gain_taxes(P, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            if (tf) { succeeded = false; years_to_ruin = (double)ry; ruin_bin = ry + 1; }  // :894-896
+            put_sample(P.trajectory_len - 1, b1 + b2, infl);                     // :897-898
+        }
+    }
+    const double final_balance = fmax(0.0, b1 + b2);  // :900, :941
+
+    // ---- outputs ----
+    if (kSummary && valid) {
+        const mcr_outputs& o = io.out;
+        if (o.start_balance) o.start_balance[li] = start_balance;
+        if (o.final_balance) o.final_balance[li] = final_balance;
+        if (o.years_to_ruin) o.years_to_ruin[li] = years_to_ruin;
+        if (o.first_year_gross_withdrawal) o.first_year_gross_withdrawal[li] = fy_gross;
+        if (o.first_year_real_gross_withdrawal) o.first_year_real_gross_withdrawal[li] = fy_real;
+        if (o.inflation_at_retirement) o.inflation_at_retirement[li] = infl_ret;
+        if (o.success) o.success[li] = succeeded ? 1 : 0;
+    }
+    // success count: wave ballot + popcount -> LDS -> one atomic per workgroup
+    const unsigned long long ok = __ballot(valid && succeeded);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&blk[0], (unsigned int)__popcll(ok));
+    const bool want_bins = io.out.ruin_year_bins != nullptr || io.out.wr_obs_counts != nullptr;
+    if (want_bins && valid) {
+        if (ruin_bin >= 0) atomicAdd(&blk[1 + ruin_bin], 1u);
+        atomicAdd(&blk[1 + (ry + 2) + done_years], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && io.out.counters) {
+        atomicAdd((unsigned long long*)&io.out.counters[MCR_CTR_SUCCESS], (unsigned long long)blk[0]);
+        const uint64_t first = (uint64_t)blockIdx.x * kBlock;
+        const uint64_t cnt = io.n_paths - first < (uint64_t)kBlock ? io.n_paths - first : (uint64_t)kBlock;
+        atomicAdd((unsigned long long*)&io.out.counters[MCR_CTR_PATHS], (unsigned long long)cnt);
+    }
+    if (want_bins) {
+        for (int k = threadIdx.x; k < ry + 2; k += kBlock) {
+            if (io.out.ruin_year_bins && blk[1 + k])
+                atomicAdd((unsigned long long*)&io.out.ruin_year_bins[k], (unsigned long long)blk[1 + k]);
+        }
+        // wr_obs_counts[y] = #paths with done_years > y   (wr_df.count(axis=1), :1111-1113)
+        for (int y = threadIdx.x; y < ry; y += kBlock) {
+            unsigned int c = 0;
+            for (int d = y + 1; d <= ry; ++d) c += blk[1 + (ry + 2) + d];
+            if (io.out.wr_obs_counts && c)
+                atomicAdd((unsigned long long*)&io.out.wr_obs_counts[y], (unsigned long long)c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device unit functions exposed for the reference's helper-level tests
+// ---------------------------------------------------------------------------------------------
+__global__ void helper_kernel(int which, const DevParams P, const double* in, double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (which) {
+        case MCR_HELPER_WITHDRAW: {
+            const double* x = in + 5 * i;
+            double bal = x[0], cb = x[1], g, nt;
+            const double rate = (x[3] != 0.0 && x[4] > 0.0) ? x[4] : 0.0;  // use_real_tax and rate > 0 (:224)
+            withdraw(bal, cb, x[2], rate, g, nt);
+            out[4 * i + 0] = bal; out[4 * i + 1] = cb; out[4 * i + 2] = g; out[4 * i + 3] = nt;
+            break;
+        }
+        case MCR_HELPER_NLV: {
+            const double* x = in + 4 * i;
+            const double rate = (x[2] != 0.0 && x[3] > 0.0) ? x[3] : 0.0;  // :269
+            out[i] = net_liquidation_value(x[0], x[1], rate);
+            break;
+        }
+        case MCR_HELPER_REBALANCE: {
+            const double* x = in + 4 * i;
+            double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
+            rebalance(P, b1, c1, b2, c2);
+            out[4 * i + 0] = b1; out[4 * i + 1] = c1; out[4 * i + 2] = b2; out[4 * i + 3] = c2;
+            break;
+        }
+        case MCR_HELPER_ANNUAL_TAX: {
+            const double* x = in + 6 * i;
+            double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
+            const bool tf = annual_gain_taxes(P, b1, c1, b2, c2, x[4], x[5]);
+            out[5 * i + 0] = b1; out[5 * i + 1] = c1; out[5 * i + 2] = b2; out[5 * i + 3] = c2;
+            out[5 * i + 4] = tf ? 1.0 : 0.0;
+            break;
+        }
+        case MCR_HELPER_MONTHLY_GROSS: {
+            const double* x = in + 3 * i;
+            out[i] = monthly_gross(x[0] / (double)kMPY, x[1] / sqrt((double)kMPY), x[2]);  // :473
+            break;
+        }
+        default: break;
+    }
+}
+
+// _draw_shock_path (:452-466): out[n_paths][n_months][3]
+__global__ void shocks_kernel(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
+                              int32_t n_months, double rho, double rho_c, double* out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = n_paths * (uint64_t)n_months;
+    if (idx >= total) return;
+    const uint64_t p = idx / (uint64_t)n_months;
+    const uint32_t m = (uint32_t)(idx % (uint64_t)n_months);
+    double ze, zi, zp;
+    shock_row(seed, stream_id, path_begin + p, m, rho, rho_c, ze, zi, zp);
+    out[3 * idx + 0] = ze; out[3 * idx + 1] = zi; out[3 * idx + 2] = zp;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return MCR_ERR_HIP;
+}
+
+int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no usable HIP device (the engine has no CPU fallback)");
+        return MCR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d devices)", device, n);
+        return MCR_ERR_INVALID_ARG;
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return MCR_OK;
+}
+
+static int query_sizes(const mcr_params* p, int32_t wm, mcr_sizes* s) {
+    if (!p || !s) { set_error("null argument"); return MCR_ERR_INVALID_ARG; }
+    if (wm < 0) { set_error("working_months must be >= 0 (got %d)", wm); return MCR_ERR_INVALID_ARG; }
+    if (p->retirement_years <= 0) { set_error("retirement_years must be > 0"); return MCR_ERR_INVALID_ARG; }
+    if (p->n_streams < 0 || p->n_streams > MCR_MAX_STREAMS) {
+        set_error("n_streams %d out of range [0, %d]", p->n_streams, MCR_MAX_STREAMS);
+        return MCR_ERR_INVALID_ARG;
+    }
+    if ((int64_t)wm + (int64_t)p->retirement_years * kMPY > (int64_t)INT32_MAX / 4) {
+        set_error("horizon too long");
+        return MCR_ERR_INVALID_ARG;
+    }
+    s->total_months = wm + p->retirement_years * kMPY;                   // simulation.py:487
+    s->shock_rows = s->total_months > 1 ? s->total_months : 1;           // :488
+    s->num_working_years = wm > 0 ? (wm + kMPY - 1) / kMPY : 0;          // :585-589
+    s->trajectory_len = 1 + s->num_working_years + p->retirement_years;  // :902
+    s->retirement_years = p->retirement_years;
+    s->ruin_bins = p->retirement_years + 2;
+    return MCR_OK;
+}
+
+// stream_payment_start_month_index (simulation.py:47-63)
+static int32_t start_month_index(double current_age, int32_t wm, double start_at_age) {
+    const double retirement_start = current_age + (double)wm / (double)kMPY;  // :34
+    const double eligible = start_at_age > retirement_start ? start_at_age : retirement_start;  // max(ret, start) :44
+    const double c = std::ceil((eligible - retirement_start) * (double)kMPY - kEps);            // :58-61
+    if (!(c > 0.0)) return 0;
+    if (c > (double)(INT32_MAX / 2)) return INT32_MAX / 2;
+    return (int32_t)c;
+}
+
+// Host-side derivation of the wave-uniform parameter block (same fp64 expressions as the reference).
+static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
+    mcr_sizes sz;
+    int rc = query_sizes(p, wm, &sz);
+    if (rc != MCR_OK) return rc;
+    std::memset(d, 0, sizeof(*d));
+    d->initial_balance = p->initial_balance;
+    d->monthly_contribution = p->monthly_contribution;
+    d->contrib_growth_factor = 1 + p->contribution_growth_rate_annual;  // :517
+    d->contrib_grows = p->contribution_growth_rate_annual > 0;          // :516
+    d->monthly_expenses = p->monthly_expenses;
+    d->alloc1 = p->allocation_inv1_pct;
+    d->alloc2 = 1.0 - p->allocation_inv1_pct;  // config.py:124-126
+    // "use_real_tax and rate > 0" (:224,:238,:269) and "if use_realized" (:304,:317): a zero rate
+    // multiplies to exactly 0.0, so one effective rate covers both spellings.
+    d->real_rate1 = (p->inv1_use_realized_gains_tax_system && p->inv1_realized_gains_tax_rate > 0) ? p->inv1_realized_gains_tax_rate : 0.0;
+    d->real_rate2 = (p->inv2_use_realized_gains_tax_system && p->inv2_realized_gains_tax_rate > 0) ? p->inv2_realized_gains_tax_rate : 0.0;
+    d->annual_rate1 = !p->inv1_use_realized_gains_tax_system ? p->inv1_annual_tax_on_gains_rate : 0.0;  // :380-384
+    d->annual_rate2 = !p->inv2_use_realized_gains_tax_system ? p->inv2_annual_tax_on_gains_rate : 0.0;  // :385-389
+    d->any_annual_tax = (d->annual_rate1 > 0.0) || (d->annual_rate2 > 0.0);
+    const double sqrt12 = std::sqrt((double)kMPY);
+    d->a1 = p->inv1_mu_log / (double)kMPY;   d->b1 = p->inv1_sigma_log / sqrt12;     // :473
+    d->ainf = p->inf_mu_log / (double)kMPY;  d->binf = p->inf_sigma_log / sqrt12;
+    d->aprem = p->prem_mu_log / (double)kMPY; d->bprem = p->prem_sigma_log / sqrt12;
+    d->rho = p->equity_inflation_rho;
+    const double om = 1.0 - d->rho * d->rho;
+    d->rho_c = std::sqrt(om > 0.0 ? om : 0.0);  // :463
+    d->working_months = wm;
+    d->retirement_years = p->retirement_years;
+    d->total_months = sz.total_months;
+    d->shock_rows = sz.shock_rows;
+    d->num_working_years = sz.num_working_years;
+    d->trajectory_len = sz.trajectory_len;
+    d->n_streams = p->n_streams;
+    int slots = 0;
+    for (int s = 0; s < p->n_streams; ++s) {
+        const mcr_stream& in = p->streams[s];
+        DevStream& o = d->streams[s];
+        o.amount = in.monthly_amount_today;
+        o.keep = 1.0 - in.tax_rate;  // :676
+        o.start_month = start_month_index(p->current_age, wm, in.start_at_age);  // :603-608
+        if (in.duration_years < 0) {
+            o.end_month = INT32_MAX;  // None: forever (:654)
+        } else {
+            const int64_t e = (int64_t)o.start_month + (int64_t)in.duration_years * kMPY;  // :609-613,:655
+            o.end_month = e > INT32_MAX ? INT32_MAX : (int32_t)e;
+        }
+        o.indexed = in.inflation_indexed ? 1 : 0;
+        o.lock_slot = o.indexed ? -1 : slots++;
+    }
+    d->n_lock_slots = slots;
+    return MCR_OK;
+}
+
+static size_t path_kernel_lds_bytes(const DevParams& d) {
+    return (size_t)d.n_lock_slots * kBlock * sizeof(double) +
+           (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1)) * sizeof(unsigned int);
+}
+
+static int launch_paths(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,
+                        uint64_t n_paths, int32_t wm, const double* injected, const mcr_outputs* out,
+                        hipStream_t stream) {
+    DevParams d;
+    int rc = derive_params(p, wm, &d);
+    if (rc != MCR_OK) return rc;
+    if (!out) { set_error("null outputs"); return MCR_ERR_INVALID_ARG; }
+    if (n_paths == 0) return MCR_OK;
+    if (n_paths > (uint64_t)INT32_MAX * kBlock) { set_error("n_paths too large for one launch"); return MCR_ERR_INVALID_ARG; }
+    if (path_begin + n_paths < path_begin) { set_error("path range overflows 64 bits"); return MCR_ERR_INVALID_ARG; }
+    const bool want_traj = out->trajectory || out->real_trajectory || out->withdrawal_rate_trajectory;
+    const bool want_summary = out->start_balance || out->final_balance || out->years_to_ruin ||
+                              out->first_year_gross_withdrawal || out->first_year_real_gross_withdrawal ||
+                              out->inflation_at_retirement || out->success;
+    KernelIO io;
+    std::memset(&io, 0, sizeof(io));
+    io.seed = seed; io.stream_id = stream_id; io.path_begin = path_begin; io.n_paths = n_paths;
+    io.injected = injected; io.out = *out;
+    if (io.out.path_stride <= 0) io.out.path_stride = (int64_t)n_paths;
+    if (want_traj && (uint64_t)io.out.path_stride < n_paths) {
+        set_error("path_stride %lld < n_paths %llu", (long long)io.out.path_stride, (unsigned long long)n_paths);
+        return MCR_ERR_INVALID_ARG;
+    }
+    const size_t lds = path_kernel_lds_bytes(d);
+    if (lds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
+    const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
+    if (want_traj)
+        hipLaunchKernelGGL(path_kernel<2>, grid, block, lds, stream, d, io);
+    else if (want_summary)
+        hipLaunchKernelGGL(path_kernel<1>, grid, block, lds, stream, d, io);
+    else
+        hipLaunchKernelGGL(path_kernel<0>, grid, block, lds, stream, d, io);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "path_kernel launch");
+    return MCR_OK;
+}
+
+}  // namespace mcr
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace mcr;
+
+extern "C" {
+
+int mcr_abi_version(void) { return MCR_ABI_VERSION; }
+
+int mcr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+const char* mcr_last_error(void) { return g_err; }
+
+int mcr_query_sizes(const mcr_params* p, int32_t working_months, mcr_sizes* out) {
+    return query_sizes(p, working_months, out);
+}
+
+int32_t mcr_stream_start_month_index(double current_age, int32_t working_months, double start_at_age) {
+    return start_month_index(current_age, working_months, start_at_age);
+}
+
+int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,
+                  uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                  const mcr_outputs* out, int device, void* hip_stream) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    return launch_paths(p, seed, stream_id, path_begin, n_paths, working_months, injected_shocks, out,
+                        (hipStream_t)hip_stream);
+}
+
+int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,
+                       uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                       const mcr_outputs* out, int device) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    mcr_sizes sz;
+    rc = query_sizes(p, working_months, &sz);
+    if (rc != MCR_OK) return rc;
+    if (!out) { set_error("null outputs"); return MCR_ERR_INVALID_ARG; }
+    if (n_paths == 0) return MCR_OK;
+    const int64_t hstride = out->path_stride > 0 ? out->path_stride : (int64_t)n_paths;
+    if ((uint64_t)hstride < n_paths) { set_error("path_stride < n_paths"); return MCR_ERR_INVALID_ARG; }
+    const size_t n = (size_t)n_paths;
+    DeviceArena arena;
+    mcr_outputs d = {};
+    d.path_stride = (int64_t)((n + 63) / 64 * 64);  // device rows padded to whole wavefronts
+    struct Copy { void* dev; void* host; size_t rows, row_bytes, dev_pitch, host_pitch; };
+    std::vector<Copy> copies;
+    hipError_t e = hipSuccess;
+    auto vec = [&](double* host, double** dev) {
+        if (!host || e != hipSuccess) return;
+        e = arena.alloc((void**)dev, n * sizeof(double));
+        copies.push_back({*dev, host, 1, n * sizeof(double), 0, 0});
+    };
+    auto mat = [&](double* host, double** dev, int rows) {
+        if (!host || e != hipSuccess) return;
+        e = arena.alloc((void**)dev, (size_t)rows * (size_t)d.path_stride * sizeof(double));
+        copies.push_back({*dev, host, (size_t)rows, n * sizeof(double),
+                          (size_t)d.path_stride * sizeof(double), (size_t)hstride * sizeof(double)});
+    };
+    vec(out->start_balance, &d.start_balance);
+    vec(out->final_balance, &d.final_balance);
+    vec(out->years_to_ruin, &d.years_to_ruin);
+    vec(out->first_year_gross_withdrawal, &d.first_year_gross_withdrawal);
+    vec(out->first_year_real_gross_withdrawal, &d.first_year_real_gross_withdrawal);
+    vec(out->inflation_at_retirement, &d.inflation_at_retirement);
+    if (out->success && e == hipSuccess) {
+        e = arena.alloc((void**)&d.success, n);
+        copies.push_back({d.success, out->success, 1, n, 0, 0});
+    }
+    mat(out->trajectory, &d.trajectory, sz.trajectory_len);
+    mat(out->real_trajectory, &d.real_trajectory, sz.trajectory_len);
+    mat(out->withdrawal_rate_trajectory, &d.withdrawal_rate_trajectory, sz.retirement_years);
+    // accumulated counters: seed the device copy with the caller's current values
+    auto acc = [&](uint64_t* host, uint64_t** dev, size_t count) {
+        if (!host || e != hipSuccess) return;
+        e = arena.alloc((void**)dev, count * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemcpy(*dev, host, count * sizeof(uint64_t), hipMemcpyHostToDevice);
+        copies.push_back({*dev, host, 1, count * sizeof(uint64_t), 0, 0});
+    };
+    acc(out->counters, &d.counters, MCR_N_COUNTERS);
+    acc(out->wr_obs_counts, &d.wr_obs_counts, (size_t)sz.retirement_years);
+    acc(out->ruin_year_bins, &d.ruin_year_bins, (size_t)sz.ruin_bins);
+    double* d_inj = nullptr;
+    if (injected_shocks && e == hipSuccess) {
+        const size_t bytes = n * (size_t)sz.shock_rows * 3 * sizeof(double);
+        e = arena.alloc((void**)&d_inj, bytes);
+        if (e == hipSuccess) e = hipMemcpy(d_inj, injected_shocks, bytes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) return hip_fail(e, "device allocation / upload");
+    rc = launch_paths(p, seed, stream_id, path_begin, n_paths, working_months, d_inj, &d, nullptr);
+    if (rc != MCR_OK) return rc;
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "path_kernel execution");
+    for (const Copy& c : copies) {
+        if (c.rows == 1) e = hipMemcpy(c.host, c.dev, c.row_bytes, hipMemcpyDeviceToHost);
+        else e = hipMemcpy2D(c.host, c.host_pitch, c.dev, c.dev_pitch, c.row_bytes, c.rows, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "download");
+    }
+    return MCR_OK;
+}
+
+int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
+                         int32_t n_months, double rho, double* out, int device) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    if (!out || n_months < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
+    const uint64_t total = n_paths * (uint64_t)n_months;
+    if (total == 0) return MCR_OK;
+    if (total > ((uint64_t)1 << 31)) { set_error("too many shock rows for one call"); return MCR_ERR_INVALID_ARG; }
+    DeviceArena arena;
+    double* d = nullptr;
+    hipError_t e = arena.alloc((void**)&d, (size_t)total * 3 * sizeof(double));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    const double om = 1.0 - rho * rho;
+    const double rho_c = std::sqrt(om > 0.0 ? om : 0.0);
+    hipLaunchKernelGGL(shocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, seed,
+                       stream_id, path_begin, n_paths, n_months, rho, rho_c, d);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "shocks_kernel");
+    return MCR_OK;
+}
+
+int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out, int64_t n, int device) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    int n_in, n_out;
+    switch (which) {
+        case MCR_HELPER_WITHDRAW: n_in = 5; n_out = 4; break;
+        case MCR_HELPER_NLV: n_in = 4; n_out = 1; break;
+        case MCR_HELPER_REBALANCE: n_in = 4; n_out = 4; break;
+        case MCR_HELPER_ANNUAL_TAX: n_in = 6; n_out = 5; break;
+        case MCR_HELPER_MONTHLY_GROSS: n_in = 3; n_out = 1; break;
+        default: set_error("unknown helper %d", which); return MCR_ERR_INVALID_ARG;
+    }
+    if (!in || !out || n < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
+    if (n == 0) return MCR_OK;
+    DevParams d;
+    std::memset(&d, 0, sizeof(d));
+    if (which == MCR_HELPER_REBALANCE || which == MCR_HELPER_ANNUAL_TAX) {
+        if (!p) { set_error("helper %d needs params", which); return MCR_ERR_INVALID_ARG; }
+        rc = derive_params(p, 0, &d);
+        if (rc != MCR_OK) return rc;
+    }
+    DeviceArena arena;
+    double *din = nullptr, *dout = nullptr;
+    hipError_t e = arena.alloc((void**)&din, (size_t)n * n_in * sizeof(double));
+    if (e == hipSuccess) e = arena.alloc((void**)&dout, (size_t)n * n_out * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(din, in, (size_t)n * n_in * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "helper upload");
+    hipLaunchKernelGGL(helper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, which, d, din, dout, n);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * n_out * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "helper_kernel");
+    return MCR_OK;
+}
+
+}  // extern "C"

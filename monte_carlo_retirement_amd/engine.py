@@ -1,0 +1,131 @@
+"""Python face of the C ABI (include/mcr.h): numpy in / numpy out, HIP underneath.
+
+Everything here runs the hand-written gfx950 kernels in csrc/ — there is no CPU path.
+Two families:
+
+* ``*_host`` helpers move small batches through host (numpy) buffers; the library
+  allocates device scratch, launches, copies back (``mcr_run_batch_host``).
+* :class:`DeviceBatch` keeps the outputs of a large batch resident in HBM (torch tensors
+  are used purely as device-memory handles / stream plumbing) for the aggregation kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _native as N
+from ._native import McrOutputs, McrParams, McrSizes
+
+SUMMARY_FIELDS = (
+    "start_balance",
+    "final_balance",
+    "years_to_ruin",
+    "first_year_gross_withdrawal",
+    "first_year_real_gross_withdrawal",
+    "inflation_at_retirement",
+)
+
+
+def query_sizes(params: McrParams, working_months: int) -> McrSizes:
+    """Shapes for (params, working_months); ``ValueError`` on invalid input."""
+    sz = McrSizes()
+    rc = N.load_library().mcr_query_sizes(C.byref(params), int(working_months), C.byref(sz))
+    if rc != 0:
+        raise ValueError(N.last_error() or "invalid params / working_months")
+    return sz
+
+
+def stream_start_month_index(current_age: float, working_months: int, start_at_age: float) -> int:
+    return int(N.load_library().mcr_stream_start_month_index(current_age, working_months, start_at_age))
+
+
+def run_batch_host(
+    params: McrParams,
+    seed: int,
+    stream_id: int,
+    path_begin: int,
+    n_paths: int,
+    working_months: int,
+    injected_shocks: Optional[np.ndarray] = None,
+    want_summary: bool = True,
+    want_trajectories: bool = True,
+    want_bins: bool = True,
+    device: int = 0,
+) -> Dict[str, np.ndarray]:
+    """Simulate paths [path_begin, path_begin+n_paths) on the GPU; numpy arrays out.
+
+    Keys follow ``mcr_outputs``: the six float summary fields + ``success`` (uint8),
+    ``trajectory``/``real_trajectory`` ``[T, n]``, ``withdrawal_rate_trajectory`` ``[ry, n]``,
+    ``counters`` ``[2]``, ``wr_obs_counts`` ``[ry]``, ``ruin_year_bins`` ``[ry+2]``.
+    """
+    lib = N.load_library()
+    N.require_device()
+    sz = query_sizes(params, working_months)
+    n = int(n_paths)
+    res: Dict[str, np.ndarray] = {}
+    o = McrOutputs()
+    o.path_stride = n
+    if want_summary:
+        for k in SUMMARY_FIELDS:
+            res[k] = np.empty(n, dtype=np.float64)
+            setattr(o, k, res[k].ctypes.data)
+        res["success"] = np.empty(n, dtype=np.uint8)
+        o.success = res["success"].ctypes.data
+    if want_trajectories:
+        res["trajectory"] = np.empty((sz.trajectory_len, n), dtype=np.float64)
+        res["real_trajectory"] = np.empty((sz.trajectory_len, n), dtype=np.float64)
+        res["withdrawal_rate_trajectory"] = np.empty((sz.retirement_years, n), dtype=np.float64)
+        o.trajectory = res["trajectory"].ctypes.data
+        o.real_trajectory = res["real_trajectory"].ctypes.data
+        o.withdrawal_rate_trajectory = res["withdrawal_rate_trajectory"].ctypes.data
+    res["counters"] = np.zeros(N.MCR_N_COUNTERS, dtype=np.uint64)
+    o.counters = res["counters"].ctypes.data
+    if want_bins:
+        res["wr_obs_counts"] = np.zeros(sz.retirement_years, dtype=np.uint64)
+        res["ruin_year_bins"] = np.zeros(sz.ruin_bins, dtype=np.uint64)
+        o.wr_obs_counts = res["wr_obs_counts"].ctypes.data
+        o.ruin_year_bins = res["ruin_year_bins"].ctypes.data
+    inj = None
+    inj_arr = None
+    if injected_shocks is not None:
+        inj_arr = np.ascontiguousarray(injected_shocks, dtype=np.float64)
+        if inj_arr.shape != (n, sz.shock_rows, 3):
+            raise ValueError(f"injected_shocks shape {inj_arr.shape} != {(n, sz.shock_rows, 3)}")
+        inj = inj_arr.ctypes.data
+    rc = lib.mcr_run_batch_host(
+        C.byref(params), int(seed), int(stream_id), int(path_begin), n, int(working_months),
+        inj, C.byref(o), int(device),
+    )
+    N.check(rc, "mcr_run_batch_host")
+    return res
+
+
+def draw_shocks_host(
+    seed: int, stream_id: int, path_begin: int, n_paths: int, n_months: int, rho: float, device: int = 0
+) -> np.ndarray:
+    """Engine shock rows ``[n_paths, n_months, 3]`` (equity, inflation, premium) from the GPU."""
+    N.require_device()
+    out = np.empty((int(n_paths), int(n_months), 3), dtype=np.float64)
+    rc = N.load_library().mcr_draw_shocks_host(
+        int(seed), int(stream_id), int(path_begin), int(n_paths), int(n_months), float(rho),
+        out.ctypes.data, int(device),
+    )
+    N.check(rc, "mcr_draw_shocks_host")
+    return out
+
+
+def eval_helper_host(which: int, params: Optional[McrParams], rows, device: int = 0) -> np.ndarray:
+    """Evaluate one of the scalar device functions (MCR_HELPER_*) on the GPU for each input row."""
+    N.require_device()
+    n_in, n_out = N.helper_arity(which)
+    a = np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, n_in))
+    out = np.empty((a.shape[0], n_out), dtype=np.float64)
+    rc = N.load_library().mcr_eval_helper_host(
+        int(which), C.byref(params) if params is not None else None, a.ctypes.data,
+        out.ctypes.data, a.shape[0], int(device),
+    )
+    N.check(rc, "mcr_eval_helper_host")
+    return out

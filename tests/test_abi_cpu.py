@@ -1,0 +1,84 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/mcr.h
+declares, its host-side derivations match the reference's, and without a GPU every compute
+entry point fails loudly (there is no CPU fallback)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+from monte_carlo_retirement_amd import Config, params_from_config
+from monte_carlo_retirement_amd import _native as N
+from monte_carlo_retirement_amd import engine as E
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from monte_carlo_retirement_amd.csrc import build
+
+    build.build()
+    return N.load_library()
+
+
+def test_header_and_binding_agree_on_symbols(lib):
+    hdr = open(os.path.join(REPO, "include", "mcr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prose in comments mentions call syntax too
+    declared = set(re.findall(r"\b(mcr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(N.ABI_SYMBOLS), declared ^ set(N.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), f"libmcr_hip.so does not export {sym}"
+    assert lib.mcr_abi_version() == N.MCR_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(N.McrStream) == 32
+    assert C.sizeof(N.McrParams) == 17 * 8 + 4 * 4 + N.MCR_MAX_STREAMS * 32
+    assert C.sizeof(N.McrSizes) == 24
+    assert C.sizeof(N.McrOutputs) == 14 * 8
+
+
+def test_host_derivations_match_reference(lib):
+    g = load_golden("helpers.json")
+    for r in g["stream_start_month_index"]:
+        assert E.stream_start_month_index(r["current_age"], r["working_months"], r["start_at_age"]) == r["start_month"]
+    cfg = Config(**load_golden("paths_injected.json")[0]["cfg"])
+    sz = E.query_sizes(params_from_config(cfg), 233)
+    assert (sz.total_months, sz.shock_rows, sz.num_working_years, sz.trajectory_len, sz.retirement_years, sz.ruin_bins) == (833, 833, 20, 71, 50, 52)
+    sz = E.query_sizes(params_from_config(cfg), 0)
+    assert (sz.total_months, sz.num_working_years, sz.trajectory_len) == (600, 0, 51)
+    with pytest.raises(ValueError):
+        E.query_sizes(params_from_config(cfg), -1)
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device the compute entry points must fail loudly, never compute on the CPU."""
+    if lib.mcr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = Config(**load_golden("paths_injected.json")[0]["cfg"])
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        E.run_batch_host(params_from_config(cfg), 1, 1, 0, 8, 12)
+    o = N.McrOutputs()
+    rc = lib.mcr_run_batch_host(C.byref(params_from_config(cfg)), 1, 1, 0, 8, 12, None, C.byref(o), 0)
+    assert rc == -2 and "no usable HIP device" in N.last_error()
+    rc = lib.mcr_run_batch(C.byref(params_from_config(cfg)), 1, 1, 0, 8, 12, None, C.byref(o), 0, None)
+    assert rc == -2
+    with pytest.raises(RuntimeError):
+        E.eval_helper_host(N.MCR_HELPER_NLV, None, [[1.0, 1.0, 0.0, 0.0]])
+    with pytest.raises(RuntimeError):
+        E.draw_shocks_host(1, 1, 0, 1, 4, 0.0)
+
+
+def test_product_package_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under monte_carlo_retirement_amd/ may reference it."""
+    root = os.path.join(REPO, "monte_carlo_retirement_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "liboracle" not in text and "mcr_oracle" not in text, f
