@@ -129,3 +129,80 @@ def eval_helper_host(which: int, params: Optional[McrParams], rows, device: int 
     )
     N.check(rc, "mcr_eval_helper_host")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Device-resident batches (torch = device memory + stream plumbing only)
+# ---------------------------------------------------------------------------------------------
+class DeviceBatch:
+    """Outputs of one (possibly multi-launch) batch kept resident in HBM.
+
+    ``want``: ``"count"`` (counters/bins only), ``"summary"`` (+ per-path fields) or
+    ``"full"`` (+ time-major trajectories).  Tensors are allocated once and reused; launches
+    go to torch's current stream through ``mcr_run_batch`` (device pointers).
+    """
+
+    def __init__(self, params: McrParams, working_months: int, n_paths: int, want: str = "count",
+                 device: int = 0):
+        import torch
+
+        if want not in ("count", "summary", "full"):
+            raise ValueError(want)
+        N.require_device()
+        self.torch = torch
+        self.params = params
+        self.working_months = int(working_months)
+        self.n_paths = int(n_paths)
+        self.want = want
+        self.device = int(device)
+        self.sizes = query_sizes(params, working_months)
+        dev = torch.device("cuda", self.device)
+        self.stride = (self.n_paths + 63) // 64 * 64
+        f64, i64 = torch.float64, torch.int64
+        self.counters = torch.zeros(N.MCR_N_COUNTERS, dtype=i64, device=dev)
+        self.wr_obs_counts = torch.zeros(self.sizes.retirement_years, dtype=i64, device=dev)
+        self.ruin_year_bins = torch.zeros(self.sizes.ruin_bins, dtype=i64, device=dev)
+        self.summary = {}
+        self.success = None
+        self.trajectory = self.real_trajectory = self.withdrawal_rate_trajectory = None
+        if want in ("summary", "full"):
+            for k in SUMMARY_FIELDS:
+                self.summary[k] = torch.empty(self.n_paths, dtype=f64, device=dev)
+            self.success = torch.empty(self.n_paths, dtype=torch.uint8, device=dev)
+        if want == "full":
+            T, ry = self.sizes.trajectory_len, self.sizes.retirement_years
+            self.trajectory = torch.empty((T, self.stride), dtype=f64, device=dev)
+            self.real_trajectory = torch.empty((T, self.stride), dtype=f64, device=dev)
+            self.withdrawal_rate_trajectory = torch.empty((ry, self.stride), dtype=f64, device=dev)
+        o = McrOutputs()
+        o.path_stride = self.stride
+        o.counters = self.counters.data_ptr()
+        o.wr_obs_counts = self.wr_obs_counts.data_ptr()
+        o.ruin_year_bins = self.ruin_year_bins.data_ptr()
+        for k, t in self.summary.items():
+            setattr(o, k, t.data_ptr())
+        if self.success is not None:
+            o.success = self.success.data_ptr()
+        if self.trajectory is not None:
+            o.trajectory = self.trajectory.data_ptr()
+            o.real_trajectory = self.real_trajectory.data_ptr()
+            o.withdrawal_rate_trajectory = self.withdrawal_rate_trajectory.data_ptr()
+        self._out = o
+        self._lib = N.load_library()
+
+    def zero_counters(self) -> None:
+        self.counters.zero_()
+        self.wr_obs_counts.zero_()
+        self.ruin_year_bins.zero_()
+
+    def launch(self, seed: int, stream_id: int, path_begin: int, n_paths: Optional[int] = None) -> None:
+        """Enqueue one kernel launch over ``n_paths`` (default: the whole batch) on the current stream."""
+        n = self.n_paths if n_paths is None else int(n_paths)
+        if n > self.n_paths:
+            raise ValueError("launch larger than the batch buffers")
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.mcr_run_batch(
+            C.byref(self.params), int(seed), int(stream_id), int(path_begin), n,
+            self.working_months, None, C.byref(self._out), self.device, C.c_void_p(stream),
+        )
+        N.check(rc, "mcr_run_batch")
