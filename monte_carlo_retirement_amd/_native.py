@@ -190,6 +190,14 @@ def load_library() -> C.CDLL:
                     "`python -c 'import __graft_entry__ as g; g.build()'` "
                     "(there is no CPU fallback)."
                 )
+            # One HIP runtime per process: PyTorch (our device-memory / stream / RCCL plumbing) ships
+            # its own libamdhip64 and looks it up by a different file name than its SONAME, so if
+            # this library pulled in the system runtime first, torch would load a second copy and
+            # find "No HIP GPUs".  Importing torch first makes both bind to the same runtime.
+            try:
+                import torch  # noqa: F401
+            except Exception:  # torch-less callers (plain ctypes integration) use the system runtime
+                pass
             try:
                 lib = C.CDLL(path)
             except OSError as exc:

@@ -1,0 +1,89 @@
+"""Device-side aggregation (csrc/mcr_aggregate.hip) with pandas/NumPy semantics.
+
+Replaces the pandas block of the reference's run_monte_carlo_simulations
+(backend/simulation.py:1045-1118): quantile bands per time point, WR observation counts,
+and the histogram of successful final balances (backend/plotting.py:53-59).
+torch tensors are device-memory handles only; all arithmetic is in the HIP kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+#: percentile sets of the reference (simulation.py:1045 and :1108-1110)
+TRAJECTORY_QUANTILES = (0.05, 0.10, 0.25, 0.50, 0.75, 0.90, 0.95)
+WR_QUANTILES = (0.05, 0.25, 0.50, 0.75, 0.95)
+
+
+def _pandas_q(qs: Sequence[float]) -> np.ndarray:
+    """pandas hands ``qs * 100`` to np.percentile, which divides by 100 again
+    (pandas/core/array_algos/quantile.py, numpy percentile): reproduce that round trip."""
+    return np.true_divide(np.asarray(qs, dtype=np.float64) * 100.0, 100)
+
+
+def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Quantiles of each row of a device tensor ``rows[n_rows, stride]`` over its first ``n``
+    entries, NaNs skipped — ``DataFrame(rows.T).quantile(qs, axis=0)`` semantics.
+
+    Returns ``(q[n_rows, len(qs)], non_nan_counts[n_rows])`` as numpy arrays.
+    """
+    import torch
+
+    assert rows.is_cuda and rows.dtype == torch.float64 and rows.dim() == 2 and rows.stride(1) == 1
+    lib = N.load_library()
+    n_rows = int(rows.shape[0])
+    q = _pandas_q(qs)
+    dev = rows.device
+    out = torch.empty((n_rows, len(q)), dtype=torch.float64, device=dev)
+    counts = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+    nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q)))
+    if nbytes <= 0:
+        raise ValueError("unsupported number of rows / quantiles")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.mcr_row_quantiles(
+        rows.data_ptr(), int(rows.stride(0)), n_rows, int(n), q.ctypes.data, len(q),
+        out.data_ptr(), counts.data_ptr(), scratch.data_ptr(), dev.index or 0, C.c_void_p(stream),
+    )
+    N.check(rc, "mcr_row_quantiles")
+    return out.cpu().numpy(), counts.cpu().numpy()
+
+
+def success_histogram(values, success, n_bins: int = 100, value_range: Optional[Tuple[float, float]] = None,
+                      reduce_range=None, reduce_bins=None):
+    """``np.histogram(values[success], bins=n_bins)`` on the device.
+
+    ``reduce_range(minmax_tensor)`` / ``reduce_bins(bins_tensor)`` are optional hooks where a
+    multi-GPU caller all-reduces (min/max, then sum) in place.  Returns ``(counts, edges)``.
+    """
+    import torch
+
+    assert values.is_cuda and success.is_cuda and values.dtype == torch.float64 and success.dtype == torch.uint8
+    lib = N.load_library()
+    dev = values.device
+    n = int(values.shape[0])
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    minmax = torch.empty(2, dtype=torch.float64, device=dev)
+    if value_range is None:
+        N.check(lib.mcr_minmax_success(values.data_ptr(), success.data_ptr(), n, minmax.data_ptr(), dev.index or 0, stream),
+                "mcr_minmax_success")
+        if reduce_range is not None:
+            reduce_range(minmax)
+    else:
+        minmax.copy_(torch.tensor(value_range, dtype=torch.float64))
+    bins = torch.zeros(n_bins, dtype=torch.int64, device=dev)
+    N.check(lib.mcr_histogram_success(values.data_ptr(), success.data_ptr(), n, minmax.data_ptr(), n_bins,
+                                      bins.data_ptr(), dev.index or 0, stream), "mcr_histogram_success")
+    if reduce_bins is not None:
+        reduce_bins(bins)
+    lo, hi = (float(x) for x in minmax.cpu().tolist())
+    if not np.isfinite(lo) or not np.isfinite(hi):  # empty cohort: numpy's default range
+        lo, hi = 0.0, 1.0
+    if lo == hi:
+        lo, hi = lo - 0.5, hi + 0.5
+    return bins.cpu().numpy(), np.linspace(lo, hi, n_bins + 1)

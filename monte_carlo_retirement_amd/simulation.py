@@ -1,0 +1,475 @@
+"""Drop-in host surface of the engine: ``RetirementMonteCarloSimulator``.
+
+Same class name, constructor, attributes, method names, argument meaning, return shapes and
+error behaviour as the reference's simulator (rflamino/monte_carlo_retirement,
+backend/simulation.py:126-1342) so FastAPI / CLI / search callers and the reference's own
+tests work unchanged — but every path is simulated by the hand-written HIP kernels in csrc/
+(through the C ABI of include/mcr.h).  There is no CPU fallback: without a gfx950 device the
+compute methods raise ``RuntimeError``.
+
+What differs, by design (documented in DESIGN.md):
+* random numbers come from a counter-based Philox4x32-10 + Box-Muller stream keyed by
+  ``main_seed`` with counter (path index, month, stream id) instead of NumPy
+  SeedSequence -> PCG64 -> ziggurat; ``path_seed`` therefore means *global path index*;
+  common random numbers across working-month candidates hold exactly as in the reference;
+* the pandas aggregation (quantile bands, counts) is computed on the device with the same
+  arithmetic (NumPy ``linear`` interpolation, NaN skipping).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+from . import _native as N
+from . import aggregation as A
+from . import engine as E
+from ._logging import logger
+from .config import Config
+from .constants import MONTHS_PER_YEAR, SMALL_EPSILON
+from .params import arithmetic_to_log_params, params_from_config
+
+__all__ = [
+    "RetirementMonteCarloSimulator",
+    "arithmetic_to_log_params",
+    "retirement_age",
+    "stream_payment_start_age",
+    "stream_payment_start_month_index",
+    "age_at_retirement_year",
+    "years_from_t0_to_age",
+    "median_first_year_withdrawal_rate",
+    "trajectory_time_points",
+]
+
+SUMMARY_COLUMNS = [  # simulation.py:1013-1024 (column order of summary_df)
+    "Start Balance",
+    "Final Balance",
+    "Success",
+    "YearsToRuin",
+    "First Year Gross Withdrawal",
+    "First Year Real Gross Withdrawal",
+    "Inflation At Retirement",
+]
+_FIELD_OF = {
+    "Start Balance": "start_balance",
+    "Final Balance": "final_balance",
+    "YearsToRuin": "years_to_ruin",
+    "First Year Gross Withdrawal": "first_year_gross_withdrawal",
+    "First Year Real Gross Withdrawal": "first_year_real_gross_withdrawal",
+    "Inflation At Retirement": "inflation_at_retirement",
+}
+
+
+# ---- module-level helpers (simulation.py:32-123) ----------------------------------------------
+def retirement_age(current_age: float, working_months: int) -> float:
+    """Age when retirement starts (simulation.py:32-34)."""
+    return current_age + working_months / MONTHS_PER_YEAR
+
+
+def stream_payment_start_age(current_age: float, working_months: int, start_at_age: float) -> float:
+    """Payments start once eligible AND retired (simulation.py:37-44)."""
+    return max(retirement_age(current_age, working_months), float(start_at_age))
+
+
+def stream_payment_start_month_index(current_age: float, working_months: int, start_at_age: float) -> int:
+    """First retirement-month index paid (simulation.py:47-63): ceil of the gap in months, with the
+    reference's 1e-6 guard so an exact month boundary does not round up."""
+    gap_years = stream_payment_start_age(current_age, working_months, start_at_age) - retirement_age(
+        current_age, working_months
+    )
+    return max(0, int(math.ceil(gap_years * MONTHS_PER_YEAR - SMALL_EPSILON)))
+
+
+def age_at_retirement_year(current_age: float, working_months: int, year_num: int) -> float:
+    """Age at the start of retirement year ``year_num`` (simulation.py:66-70)."""
+    return retirement_age(current_age, working_months) + year_num
+
+
+def years_from_t0_to_age(current_age: float, target_age: float) -> float:
+    """Years from T=0 until ``target_age`` (simulation.py:73-75)."""
+    return max(0.0, float(target_age) - float(current_age))
+
+
+def median_first_year_withdrawal_rate(summary_df: pd.DataFrame) -> float:
+    """Median over paths (start balance > eps) of first-year real gross withdrawal / start
+    balance, in percent (simulation.py:78-96)."""
+    if summary_df.empty:
+        return float("nan")
+    col = (
+        "First Year Real Gross Withdrawal"
+        if "First Year Real Gross Withdrawal" in summary_df.columns
+        else "First Year Gross Withdrawal"
+    )
+    start = summary_df["Start Balance"]
+    keep = start > SMALL_EPSILON
+    if not keep.any():
+        return float("nan")
+    return float(((summary_df[col][keep] / start[keep]) * 100.0).median())
+
+
+def trajectory_time_points(working_months: int, retirement_years: int) -> List[float]:
+    """Year values of the yearly trajectory samples (simulation.py:99-123)."""
+    full_years, leftover = divmod(working_months, MONTHS_PER_YEAR)
+    t_ret = working_months / MONTHS_PER_YEAR
+    pts = [0.0] + [float(y) for y in range(1, full_years + 1)]
+    if leftover:
+        pts.append(t_ret)
+    pts.extend(t_ret + y for y in range(1, retirement_years + 1))
+    return pts
+
+
+def _fold_seed_u64(seed: int) -> int:
+    """Philox key = the seed folded to 64 bits (seeds are unbounded Python ints in the Config)."""
+    s, out = int(seed), 0
+    while True:
+        out ^= s & 0xFFFFFFFFFFFFFFFF
+        s >>= 64
+        if s == 0:
+            return out
+
+
+class RetirementMonteCarloSimulator:
+    """Monte Carlo retirement simulator whose paths run on an MI355X (see module docstring)."""
+
+    def __init__(self, params_model: Config, main_seed_override: Optional[int] = None, device: int = 0):
+        self.params_model = params_model.model_copy(deep=True)  # simulation.py:136
+
+        if main_seed_override is not None:  # :138-145
+            if main_seed_override < 0:
+                raise ValueError("main_seed_override must be nonnegative.")
+            self.main_seed = main_seed_override
+        elif self.params_model.seed is not None:
+            self.main_seed = self.params_model.seed
+        else:
+            self.main_seed = _seed_from_timestamp()
+
+        # Two independent streams (search vs final run, :147-151): the stream id is one word of the
+        # Philox counter, so the streams never overlap.
+        self._stream_name = "final"
+        self._engine_seed = _fold_seed_u64(self.main_seed)
+        self.device = int(device)
+
+        p = self.params_model
+        self._inv1_mu_log, self._inv1_sigma_log = arithmetic_to_log_params(  # :157-166
+            p.inv1_returns_mean, p.inv1_returns_volatility
+        )
+        self._inf_mu_log, self._inf_sigma_log = arithmetic_to_log_params(
+            p.inflation_rate_mean, p.inflation_rate_volatility
+        )
+        self._inv2_prem_mu_log, self._inv2_prem_sigma_log = arithmetic_to_log_params(
+            p.inv2_premium_over_inflation_mean, p.inv2_premium_over_inflation_volatility
+        )
+        self._equity_inflation_rho = p.equity_inflation_correlation  # :170
+        self._params = params_from_config(p)
+        logger.info(
+            f"Simulator initialized for scenario '{p.Nickname}' with main seed: {self.main_seed}"
+        )
+
+    # ---- seed streams (:177-199) ---------------------------------------------------------------
+    @property
+    def _stream_id(self) -> int:
+        return N.MCR_STREAM_SEARCH if self._stream_name == "search" else N.MCR_STREAM_FINAL
+
+    def use_search_seeds(self) -> None:
+        self._stream_name = "search"
+
+    def use_final_seeds(self) -> None:
+        self._stream_name = "final"
+
+    def _path_seeds(self, num_simulations: int) -> List[int]:
+        """Path identifiers of a batch.  In this engine a path's "seed" is its global index in the
+        active stream: the same list for every working-month candidate (common random numbers)."""
+        return list(range(int(num_simulations)))
+
+    # ---- scalar helpers: evaluated by the SAME device functions the path kernel inlines -----------
+    def _calculate_withdrawal_and_update(
+        self, bal_inv: float, cb_inv: float, net_withdrawal_target_for_inv: float,
+        use_real_tax: bool, real_tax_rate: float,
+    ) -> Tuple[float, float, float, float]:
+        """(new_balance, new_cost_basis, gross_withdrawal, net_cash) — simulation.py:201-254."""
+        r = E.eval_helper_host(
+            N.MCR_HELPER_WITHDRAW, None,
+            [[bal_inv, cb_inv, net_withdrawal_target_for_inv, 1.0 if use_real_tax else 0.0, real_tax_rate]],
+            self.device,
+        )[0]
+        return float(r[0]), float(r[1]), float(r[2]), float(r[3])
+
+    def _net_liquidation_value(
+        self, balance: float, cost_basis: float, use_realized_gains_tax: bool, realized_gains_tax_rate: float
+    ) -> float:
+        """Cash after liquidating an asset and paying gains tax — simulation.py:256-272."""
+        return float(E.eval_helper_host(
+            N.MCR_HELPER_NLV, None,
+            [[balance, cost_basis, 1.0 if use_realized_gains_tax else 0.0, realized_gains_tax_rate]],
+            self.device,
+        )[0][0])
+
+    def _rebalance_portfolio(
+        self, bal_inv1: float, cb_inv1: float, bal_inv2: float, cb_inv2: float
+    ) -> Tuple[float, float, float, float]:
+        """Tax-aware rebalance to the target allocation — simulation.py:274-359."""
+        r = E.eval_helper_host(N.MCR_HELPER_REBALANCE, self._current_params(),
+                               [[bal_inv1, cb_inv1, bal_inv2, cb_inv2]], self.device)[0]
+        return float(r[0]), float(r[1]), float(r[2]), float(r[3])
+
+    def _apply_annual_gain_taxes(
+        self, balance_inv1: float, cost_basis_inv1: float, balance_inv2: float, cost_basis_inv2: float,
+        gain_inv1: float, gain_inv2: float,
+    ) -> Tuple[float, float, float, float, bool]:
+        """Annual mark-to-market tax for one period — simulation.py:361-450."""
+        r = E.eval_helper_host(
+            N.MCR_HELPER_ANNUAL_TAX, self._current_params(),
+            [[balance_inv1, cost_basis_inv1, balance_inv2, cost_basis_inv2, gain_inv1, gain_inv2]],
+            self.device,
+        )[0]
+        return float(r[0]), float(r[1]), float(r[2]), float(r[3]), bool(r[4])
+
+    def _monthly_gross_from_shock(self, mu_log: float, sigma_log: float, z: float) -> float:
+        """exp(mu/12 + sigma/sqrt(12) z) — simulation.py:468-474."""
+        return float(E.eval_helper_host(N.MCR_HELPER_MONTHLY_GROSS, None, [[mu_log, sigma_log, z]], self.device)[0][0])
+
+    def _draw_shock_path(self, n_months: int, path_seed: int) -> np.ndarray:
+        """Shock rows (equity, inflation, premium) of one path, shape (n_months, 3) — the engine's
+        replacement of simulation.py:452-466."""
+        return E.draw_shocks_host(
+            self._engine_seed, self._stream_id, int(path_seed), 1, int(n_months), self._equity_inflation_rho,
+            self.device,
+        )[0]
+
+    def _current_params(self):
+        """The parameter block of the *current* params_model (validate_assignment lets callers
+        mutate the config between runs, as they can in the reference)."""
+        self._params = params_from_config(self.params_model)
+        return self._params
+
+    # ---- one path (:476-950) -------------------------------------------------------------------
+    def _run_single_simulation_path(
+        self, working_months: int, path_seed: int
+    ) -> Dict[str, Union[float, List[float]]]:
+        """Simulate ONE path on the device and return the reference's 10-key dict."""
+        r = E.run_batch_host(
+            self._current_params(), self._engine_seed, self._stream_id, int(path_seed), 1,
+            int(working_months), want_bins=False, device=self.device,
+        )
+        return {
+            "Start Balance": float(r["start_balance"][0]),
+            "Final Balance": float(r["final_balance"][0]),
+            "Success": bool(r["success"][0]),
+            "YearsToRuin": float(r["years_to_ruin"][0]),
+            "First Year Gross Withdrawal": float(r["first_year_gross_withdrawal"][0]),
+            "First Year Real Gross Withdrawal": float(r["first_year_real_gross_withdrawal"][0]),
+            "Trajectory": r["trajectory"][:, 0].tolist(),
+            "RealTrajectory": r["real_trajectory"][:, 0].tolist(),
+            "WithdrawalRateTrajectory": r["withdrawal_rate_trajectory"][:, 0].tolist(),
+            "Inflation At Retirement": float(r["inflation_at_retirement"][0]),
+        }
+
+    # ---- batch driver (:952-1128) --------------------------------------------------------------
+    def run_monte_carlo_simulations(
+        self, working_months: int, num_simulations: int
+    ) -> Tuple[
+        pd.DataFrame,
+        Optional[pd.DataFrame],
+        Optional[List[List[float]]],
+        Optional[pd.DataFrame],
+        Optional[pd.DataFrame],
+        Optional[List[List[float]]],
+        Optional[List[int]],
+    ]:
+        """Simulate ``num_simulations`` paths in ONE kernel launch and aggregate on the device.
+
+        Returns the reference's 7-tuple: ``(summary_df, trajectory_percentiles_df,
+        sample_trajectories, wr_percentiles_df, real_trajectory_percentiles_df,
+        sample_real_trajectories, wr_observation_counts)``.
+        """
+        n = int(num_simulations)
+        wm = int(working_months)
+        logger.debug(f"Running {n} simulations on HIP device {self.device} for {wm} working months.")
+        batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=self.device)
+        batch.launch(self._engine_seed, self._stream_id, 0)
+
+        cols = {name: batch.summary[field].cpu().numpy() for name, field in _FIELD_OF.items()}
+        cols["Success"] = batch.success.cpu().numpy().astype(bool)
+        summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
+
+        traj_q, _ = A.row_quantiles(batch.trajectory, n, A.TRAJECTORY_QUANTILES)
+        real_q, _ = A.row_quantiles(batch.real_trajectory, n, A.TRAJECTORY_QUANTILES)
+        wr_q, wr_counts = A.row_quantiles(batch.withdrawal_rate_trajectory, n, A.WR_QUANTILES)
+        qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
+        trajectory_percentiles_df = pd.DataFrame(traj_q, columns=qcols)
+        real_trajectory_percentiles_df = pd.DataFrame(real_q, columns=qcols)
+        wr_percentiles_df = pd.DataFrame(wr_q, columns=pd.Index(list(A.WR_QUANTILES), dtype="float64"))
+        wr_observation_counts = [int(v) for v in wr_counts.tolist()]
+
+        # 5 sample paths: the columns trajectory_df.sample(n=5, axis=1, random_state=main_seed) picks
+        # (:1063-1078).  pandas draws them with RandomState(seed).choice(n, 5, replace=False).
+        sample_trajectories_list: Optional[List[List[float]]] = None
+        sample_real_trajectories_list: Optional[List[List[float]]] = None
+        k = min(n, 5)
+        if k > 0:
+            try:
+                picked = np.random.RandomState(self.main_seed).choice(n, size=k, replace=False)
+                idx = batch.torch.as_tensor(picked, device=batch.trajectory.device, dtype=batch.torch.long)
+                sample_trajectories_list = batch.trajectory.index_select(1, idx).T.cpu().numpy().tolist()
+                sample_real_trajectories_list = batch.real_trajectory.index_select(1, idx).T.cpu().numpy().tolist()
+            except ValueError as ve:  # e.g. main_seed >= 2**32: the reference logs and returns None (:1079-1083)
+                logger.error(f"Error sampling trajectories: {ve}")
+        return (
+            summary_df,
+            trajectory_percentiles_df,
+            sample_trajectories_list,
+            wr_percentiles_df,
+            real_trajectory_percentiles_df,
+            sample_real_trajectories_list,
+            wr_observation_counts,
+        )
+
+    def _success_probability(self, summary_df: pd.DataFrame) -> float:
+        """Share of paths that funded all spending, in percent (simulation.py:1130-1136)."""
+        if summary_df.empty:
+            return 0.0
+        if "Success" in summary_df.columns:
+            return float(summary_df["Success"].astype(bool).mean() * 100.0)
+        return float((summary_df["Final Balance"] > SMALL_EPSILON).mean() * 100.0)
+
+    # ---- count-only probe used by the search ------------------------------------------------------
+    def _probe_success_probability(self, working_months: int, num_simulations: int) -> float:
+        """Success % of a batch from the count-only kernel (no per-path HBM traffic).  Equals
+        ``_success_probability(run_monte_carlo_simulations(...)[0])`` bit-for-bit: count/n*100."""
+        n = int(num_simulations)
+        batch = E.DeviceBatch(self._current_params(), int(working_months), n, want="count", device=self.device)
+        batch.launch(self._engine_seed, self._stream_id, 0)
+        ok = int(batch.counters[N.MCR_CTR_SUCCESS].item())
+        return float(np.float64(ok) / np.float64(n) * 100.0)
+
+    # ---- search driver (:1138-1342) ------------------------------------------------------------
+    def find_minimum_working_months(
+        self,
+        verbose: bool = True,
+        progress_callback: Optional[Callable[[dict], None]] = None,
+    ) -> Tuple[int, float, List[Dict[str, float]]]:
+        """Smallest working-month count reaching the target success probability.
+
+        Same procedure as the reference: coarse bracket (step 12, grown to 24 while > 20 points
+        short), bisection, then every month of the statistically plausible window is verified
+        (3-sigma binomial margin) because Monte Carlo estimates are locally non-monotone.  Uses the
+        search stream with common random numbers.  Returns ``(months, probability, search_curve)``;
+        ``months == -1`` when the target is not reachable within 70 years.
+        """
+        self.use_search_seeds()
+        p = self.params_model
+        first = p.starting_working_months_search
+        target = p.target_probability
+        n_sims = p.num_simulations_search
+        horizon = first + 70 * MONTHS_PER_YEAR
+        curve: List[Dict[str, float]] = []
+        memo: Dict[int, float] = {}
+        state = {"iter": 0, "best_seen": -1.0, "lo": first, "hi": None}
+        # the reference's tests (and callers) may replace run_monte_carlo_simulations per instance;
+        # then the search must go through it.  Otherwise use the count-only kernel.
+        patched = "run_monte_carlo_simulations" in self.__dict__
+
+        if verbose:
+            logger.info(f"Estimating working months to achieve {target:.2f}% success for '{p.Nickname}'.")
+            logger.info(f"Starting search from {first} months. Simulations per test: {n_sims}.")
+
+        def probe(months: int) -> float:
+            if months in memo:
+                return memo[months]
+            state["iter"] += 1
+            if verbose:
+                logger.info(f"Search iter {state['iter']}: Testing {months} m "
+                            f"({months / MONTHS_PER_YEAR:.1f} yrs) with {n_sims} sims.")
+            if patched:
+                summary_df = self.run_monte_carlo_simulations(months, n_sims)[0]
+                prob = self._success_probability(summary_df)
+            else:
+                prob = self._probe_success_probability(months, n_sims)
+            memo[months] = prob
+            if verbose:
+                logger.info(f"  Search iter {state['iter']}: Prob for {months} m: {prob:.2f}% (Target: {target:.2f}%)")
+            years = round(months / MONTHS_PER_YEAR, 1)
+            curve.append({"working_months": months, "working_years": years, "probability": round(prob, 2)})
+            if progress_callback:
+                progress_callback({
+                    "type": "search_iter", "iteration": state["iter"], "working_months": months,
+                    "working_years": years, "probability": round(prob, 2), "target": target,
+                    "sim_count": n_sims, "lo": state["lo"], "hi": state["hi"],
+                })
+            state["best_seen"] = max(state["best_seen"], prob)
+            return prob
+
+        # phase 1: bracket
+        step = 12
+        at = first
+        prob_lo = probe(at)
+        if prob_lo >= target:
+            if verbose:
+                logger.info(f"  Target met at starting point {at} months.")
+            return at, prob_lo, curve
+        best_prob = prob_lo
+        while at < horizon:
+            shortfall = target - prob_lo
+            step = max(step, 24 if shortfall > 20 else (12 if shortfall > 10 else 6))
+            nxt = min(at + step, horizon)
+            if nxt <= at:
+                break
+            prob = probe(nxt)
+            if prob >= target:
+                state["lo"], state["hi"], best_prob = at, nxt, prob
+                if verbose:
+                    logger.info(f"  Bracketed: lo={at} m (miss), hi={nxt} m (hit). Bisecting…")
+                if progress_callback:
+                    progress_callback({"type": "search_refining", "working_months": nxt, "lo": at, "hi": nxt})
+                break
+            state["lo"] = nxt
+            prob_lo = prob
+            at = nxt
+        if state["hi"] is None:
+            if verbose:
+                logger.warning(f"Search for '{p.Nickname}' reached max limit "
+                               f"({horizon / MONTHS_PER_YEAR:.1f} yrs). Target NOT met.")
+                logger.warning(f"Highest probability achieved: {state['best_seen']:.2f}%.")
+            return -1, state["best_seen"], curve
+
+        # phase 2: bisect, remembering the smallest month that met the target
+        best = state["hi"]
+        while state["hi"] - state["lo"] > 1:
+            mid = (state["lo"] + state["hi"]) // 2
+            prob = probe(mid)
+            if prob >= target:
+                best, best_prob = mid, prob
+                state["hi"] = mid
+            else:
+                state["lo"] = mid
+
+        # phase 3: verify every month from one tested point before the first plausible month
+        margin = min(100.0, 150.0 / math.sqrt(n_sims))
+        tested = sorted(m for m in memo if m <= best)
+        near = next((i for i, m in enumerate(tested) if memo[m] >= target - margin), len(tested) - 1)
+        verify_from = max(first, tested[max(0, near - 1)])
+        if verbose:
+            logger.info(f"  Verifying each month from {verify_from} to {best} "
+                        "to handle locally non-monotone Monte Carlo estimates.")
+        for month in range(verify_from, best + 1):
+            probe(month)
+        hits = [m for m, pr in memo.items() if first <= m <= best and pr >= target]
+        if hits:
+            best = min(hits)
+            best_prob = memo[best]
+        if verbose:
+            logger.info(f"  Search complete: estimated minimum {best} months "
+                        f"({best / MONTHS_PER_YEAR:.1f} yrs) with prob {best_prob:.2f}%.")
+        return best, best_prob, curve
+
+
+def _seed_from_timestamp() -> int:
+    """Seed when none is configured: hash of the UTC timestamp (backend/utils.py:16-18)."""
+    import datetime as _dt
+    import hashlib
+
+    ts = _dt.datetime.now(_dt.timezone.utc).isoformat()
+    return int.from_bytes(hashlib.sha256(ts.encode()).digest()[:8], "big") % (2**32 - 1)

@@ -1,0 +1,227 @@
+"""The drop-in simulator class on a real MI355X: the reference's own test scenarios
+(tests/test_simulation_correctness.py) re-stated against this engine, the aggregation block vs
+pandas goldens, and the full search vs the reference's recorded search."""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import STREAM_ID, load_golden
+from monte_carlo_retirement_amd import Config
+from monte_carlo_retirement_amd.constants import MONTHS_PER_YEAR, SMALL_EPSILON
+from monte_carlo_retirement_amd.simulation import (
+    SUMMARY_COLUMNS,
+    RetirementMonteCarloSimulator,
+    median_first_year_withdrawal_rate,
+    trajectory_time_points,
+)
+
+pytestmark = pytest.mark.gpu
+
+
+def _det(name):
+    return [c for c in load_golden("paths_deterministic.json") if c["name"] == name][0]
+
+
+def _sim(case, **kw):
+    return RetirementMonteCarloSimulator(Config(**case["cfg"]), **kw)
+
+
+def test_partial_year_inflation_accrual():  # reference :84-107
+    c = _det("partial_year_inflation_accrual")
+    r = _sim(c)._run_single_simulation_path(13, path_seed=99)
+    assert abs(r["Inflation At Retirement"] - 1.06 ** (13 / MONTHS_PER_YEAR)) < 1e-9
+    pts = trajectory_time_points(13, 1)
+    assert pts == pytest.approx([0.0, 1.0, 13 / 12, 25 / 12]) and len(pts) == len(r["Trajectory"])
+
+
+def test_partial_year_trajectory_keeps_equal_retirement_balance():  # :110-134
+    r = _sim(_det("partial_year_equal_retirement_balance"))._run_single_simulation_path(working_months=13, path_seed=1)
+    assert r["Trajectory"] == pytest.approx([100_000.0, 100_000.0, 100_000.0, 88_000.0])
+    assert r["RealTrajectory"] == pytest.approx(r["Trajectory"])
+
+
+def test_allocation_weights_conserve_every_dollar():  # :198-217
+    r = _sim(_det("allocation_weights_conserve"))._run_single_simulation_path(working_months=0, path_seed=1)
+    assert r["Start Balance"] == pytest.approx(100_000.0) and r["Trajectory"][0] == pytest.approx(100_000.0)
+
+
+def test_perfect_equity_inflation_correlation_is_preserved():  # :185-195
+    base = _det("years_to_ruin")["cfg"]
+    pos = RetirementMonteCarloSimulator(Config(**dict(base, equity_inflation_correlation=1.0)))._draw_shock_path(100, path_seed=4)
+    assert pos.shape == (100, 3) and pos[:, 1] == pytest.approx(pos[:, 0])
+    neg = RetirementMonteCarloSimulator(Config(**dict(base, equity_inflation_correlation=-1.0)))._draw_shock_path(100, path_seed=4)
+    assert neg[:, 1] == pytest.approx(-neg[:, 0])
+
+
+def test_income_stream_cases():  # :363-404, :407-441, :444-493
+    with_p = _sim(_det("income_stream_starts_at_age"))._run_single_simulation_path(240, 1)
+    without = _sim(_det("income_stream_starts_at_age_no_pension"))._run_single_simulation_path(240, 1)
+    assert with_p["Final Balance"] > 0 and with_p["Final Balance"] > without["Final Balance"]
+    r = _sim(_det("income_stream_fractional_age"))._run_single_simulation_path(0, 4)
+    assert r["Success"] is True and r["Final Balance"] == pytest.approx(0.0, abs=1e-6)
+    assert r["First Year Gross Withdrawal"] == pytest.approx(6_000.0)
+    sim = _sim(_det("pension_covers_after_depletion"))
+    r = sim._run_single_simulation_path(0, 1)
+    assert r["Success"] is True and r["Final Balance"] == pytest.approx(0.0, abs=1e-6)
+    assert _sim(_det("pension_covers_after_depletion_no_pension"))._run_single_simulation_path(0, 1)["Success"] is False
+    sim.use_final_seeds()
+    summary = sim.run_monte_carlo_simulations(0, 5)[0]
+    assert sim._success_probability(summary) == pytest.approx(100.0)
+    assert (summary["Final Balance"] <= SMALL_EPSILON).all()
+
+
+def test_withdrawal_rate_cases():  # :220-256, :496-564
+    c = _det("withdrawal_rate_first_year")
+    sim = _sim(c)
+    r = sim._run_single_simulation_path(0, 1)
+    wr = r["WithdrawalRateTrajectory"]
+    expected = (r["First Year Gross Withdrawal"] / r["Start Balance"]) * 100.0
+    assert len(wr) == 5 and wr[0] == pytest.approx(expected, abs=1e-6) and wr[1] == pytest.approx(wr[0], abs=1e-6)
+    summary, _, _, wr_pct, _, _, wr_counts = sim.run_monte_carlo_simulations(0, 10)
+    assert wr_pct is not None and not wr_pct.empty and wr_counts == [10] * 5
+    assert abs(wr_pct.iloc[0][0.50] - expected) < 0.5
+    assert abs(median_first_year_withdrawal_rate(summary) - wr_pct.iloc[0][0.50]) < 0.5
+    sim.use_final_seeds()
+    summary = sim.run_monte_carlo_simulations(working_months=0, num_simulations=20)[0]  # keyword call (server.py:431-434)
+    assert abs(median_first_year_withdrawal_rate(summary) - 6.0) < 0.5
+    for _, row in summary.iterrows():
+        assert abs(row["First Year Gross Withdrawal"] - 12_000.0) < 1.0
+    r = _sim(_det("real_wr_flat_deterministic_inflation"))._run_single_simulation_path(0, 3)
+    assert r["Success"] is True and r["WithdrawalRateTrajectory"][0] == pytest.approx(5.0, abs=0.05)
+    for rate in r["WithdrawalRateTrajectory"]:
+        assert rate == pytest.approx(r["WithdrawalRateTrajectory"][0], abs=1e-4)
+
+
+def test_years_to_ruin_and_real_trajectory():  # :567-602
+    sim = _sim(_det("years_to_ruin"))
+    r = sim._run_single_simulation_path(0, 1)
+    assert r["Success"] is False and r["YearsToRuin"] == pytest.approx(3 / 12)
+    assert len(r["RealTrajectory"]) == len(r["Trajectory"])
+    for nom, real in zip(r["Trajectory"], r["RealTrajectory"]):
+        assert real == pytest.approx(nom, abs=1e-6)
+    summary, traj, _, _, real_traj, _, wr_counts = sim.run_monte_carlo_simulations(0, 20)
+    assert (summary["Success"] == False).all() and summary["YearsToRuin"].notna().all()  # noqa: E712
+    assert real_traj is not None and traj is not None and len(real_traj) == len(traj)
+    assert wr_counts == [0] * 10
+
+
+def test_helper_methods_unit_pins():  # :605-662
+    sim = RetirementMonteCarloSimulator(Config(**load_golden("helpers.json")["tax_cfgs"][0]))
+    assert sim._calculate_withdrawal_and_update(100.0, 0.0, 90.0, True, 0.20) == pytest.approx((0.0, 0.0, 100.0, 80.0))
+    assert sim._calculate_withdrawal_and_update(80.0, 100.0, 40.0, True, 0.20) == pytest.approx((40.0, 50.0, 40.0, 40.0))
+    b1, c1, b2, c2 = sim._rebalance_portfolio(bal_inv1=70.0, cb_inv1=50.0, bal_inv2=30.0, cb_inv2=30.0)
+    assert b1 / (b1 + b2) == pytest.approx(0.60, abs=1e-10) and b1 + b2 < 100.0
+    assert sim._net_liquidation_value(100.0, 0.0, True, 0.2) == pytest.approx(80.0)
+    assert sim._monthly_gross_from_shock(0.12, 0.0, 1.0) == pytest.approx(math.exp(0.01))
+    out = sim._apply_annual_gain_taxes(60.0, 60.0, 40.0, 40.0, 0.0, 0.0)
+    assert out[:4] == pytest.approx((60.0, 60.0, 40.0, 40.0)) and out[4] is False
+
+
+def test_annual_tax_cases():  # :665-734
+    a = _sim(_det("annual_tax_excludes_transfers_no_tax"))._run_single_simulation_path(12, 1)
+    b = _sim(_det("annual_tax_excludes_transfers_full_tax"))._run_single_simulation_path(12, 1)
+    assert b["Start Balance"] == pytest.approx(a["Start Balance"], rel=1e-10)
+    assert b["Final Balance"] == pytest.approx(a["Final Balance"], rel=1e-10)
+    r = _sim(_det("retirement_does_not_split_tax_period"))._run_single_simulation_path(13, 1)
+    assert r["Start Balance"] == pytest.approx((112.0 - 6.0) * 1.12 ** (1 / 12), rel=1e-10)
+
+
+def test_success_probability_non_decreasing_in_working_months():  # :55-81
+    g = load_golden("search.json")[1]
+    sim = RetirementMonteCarloSimulator(Config(**dict(g["cfg"], num_simulations_main=80, seed=123)))
+    sim.use_search_seeds()
+    probs = [sim._success_probability(sim.run_monte_carlo_simulations(m, 80)[0]) for m in range(0, 61, 6)]
+    assert all(b + 1e-9 >= a for a, b in zip(probs, probs[1:])), probs
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_aggregation_matches_pandas_on_reference_batch(idx):
+    """a12: the 7-tuple for a 200-path batch vs the reference (same shocks).  Quantile frames use
+    the same order statistics + NumPy-linear arithmetic: rel 1e-9 (path tolerance)."""
+    g = load_golden("aggregation.json")[idx]
+    sim = RetirementMonteCarloSimulator(Config(**g["cfg"]), main_seed_override=g["seed"])
+    getattr(sim, f"use_{g['stream']}_seeds")()
+    summary, traj, samples, wr, real, real_samples, wr_counts = sim.run_monte_carlo_simulations(g["working_months"], g["n_paths"])
+    assert list(summary.columns) == SUMMARY_COLUMNS and summary["Success"].dtype == bool
+    assert summary["Success"].tolist() == g["summary"]["Success"]
+    for k in SUMMARY_COLUMNS:
+        if k != "Success":
+            np.testing.assert_allclose(summary[k].to_numpy(), np.array(g["summary"][k]), rtol=1e-9, atol=1e-6, equal_nan=True, err_msg=k)
+    assert sim._success_probability(summary) == g["success_probability"]
+    assert median_first_year_withdrawal_rate(summary) == pytest.approx(g["median_first_year_withdrawal_rate"], rel=1e-9)
+    for frame, key in ((traj, "trajectory_percentiles"), (real, "real_trajectory_percentiles"), (wr, "wr_percentiles")):
+        exp = g[key]
+        assert [float(c) for c in frame.columns] == exp["columns"]
+        assert list(frame.index) == list(range(len(exp["values"])))
+        np.testing.assert_allclose(frame.to_numpy(), np.array(exp["values"], dtype=float), rtol=1e-9, atol=1e-6, equal_nan=True, err_msg=key)
+    assert wr_counts == g["wr_observation_counts"]
+    # the 5 sampled columns are the ones pandas picks for this main_seed
+    np.testing.assert_allclose(np.array(samples), np.array(g["sample_trajectories"]), rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(np.array(real_samples), np.array(g["sample_real_trajectories"]), rtol=1e-9, atol=1e-6)
+
+
+def test_row_quantiles_match_pandas_exactly_on_random_rows():
+    """K3 against pandas on synthetic rows with NaNs, ties, infinities, ragged strides: BIT-exact
+    (order statistics are exact; interpolation uses NumPy's own arithmetic)."""
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    rng = np.random.default_rng(5)
+    for n, stride in [(1, 64), (2, 64), (7, 64), (200, 256), (1001, 1024), (50_000, 50_048)]:
+        rows = np.full((9, stride), 123.0)
+        rows[0, :n] = rng.normal(1e6, 3e5, n)
+        rows[1, :n] = rng.integers(0, 5, n).astype(float)          # heavy ties
+        rows[2, :n] = np.where(rng.random(n) < 0.3, np.nan, rng.lognormal(0, 2, n))
+        rows[3, :n] = np.nan                                        # all-NaN row
+        rows[4, :n] = -rng.lognormal(3, 1, n)                       # negatives
+        rows[5, :n] = 0.0
+        rows[6, :n] = rng.choice([-np.inf, np.inf, 0.0, -0.0, 1e-300, -1e-300, 5.0], n)
+        rows[7, :n] = np.arange(n, dtype=float)
+        rows[8, :n] = rng.normal(0, 1, n) * 10.0 ** rng.integers(-8, 9, n)
+        got, counts = A.row_quantiles(torch.as_tensor(rows, device="cuda"), n, A.TRAJECTORY_QUANTILES)
+        exp = pd.DataFrame(rows[:, :n].T).quantile(list(A.TRAJECTORY_QUANTILES), axis=0).T.to_numpy()
+        assert np.array_equal(got, exp, equal_nan=True), (n, got, exp)
+        assert counts.tolist() == (~np.isnan(rows[:, :n])).sum(axis=1).tolist()
+
+
+def test_success_histogram_matches_numpy():
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    rng = np.random.default_rng(11)
+    for n in (1, 5, 1000, 300_000):
+        v = rng.lognormal(14, 1, n)
+        ok = (rng.random(n) < 0.8).astype(np.uint8)
+        if n == 5:
+            v[:] = 7.0
+        got, edges = A.success_histogram(torch.as_tensor(v, device="cuda"), torch.as_tensor(ok, device="cuda"), 100)
+        sel = v[ok.astype(bool)]
+        if sel.size == 0:
+            assert got.sum() == 0
+            continue
+        exp, exp_edges = np.histogram(sel, bins=100)
+        assert got.tolist() == exp.tolist()
+        np.testing.assert_allclose(edges, exp_edges, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_full_search_matches_reference(idx):
+    """Search driver end-to-end on the GPU (count-only probes) vs the reference's recorded search on
+    the same shocks: same probes, same curve, same result."""
+    g = load_golden("search.json")[idx]
+    sim = RetirementMonteCarloSimulator(Config(**g["cfg"]), main_seed_override=g["seed"])
+    events = []
+    months, prob, curve = sim.find_minimum_working_months(verbose=False, progress_callback=events.append)
+    assert (months, prob) == (g["months"], g["probability"])
+    assert curve == g["search_curve"]
+    assert events == g["events"]
+    # the count-only probe equals the full run's success probability bit-for-bit
+    full = sim._success_probability(sim.run_monte_carlo_simulations(months, sim.params_model.num_simulations_search)[0])
+    assert full == prob
