@@ -1,0 +1,128 @@
+"""Multi-GPU execution: one process per GPU, independent path ranges, ONE all-reduce.
+
+The reference has no distributed code (its only parallelism is a ``multiprocessing.Pool`` over
+independent paths, backend/simulation.py:996-1001).  Here the global path range ``[0, N)`` is
+cut into contiguous shards, one per rank; the Philox counter carries the GLOBAL path index, so
+the union of the shards is bit-identical to a single-GPU run.  The only exchange step is a
+sum all-reduce of one small int64 vector ``[success, paths, wr_obs_counts[ry], ruin_bins[ry+2]]``
+(RCCL over xGMI when the backend is "nccl"; latency-bound, < 2 KB) — plus, for the histogram of
+final balances, a min/max all-reduce of two doubles before the bins are summed.
+Trajectories never leave the GPU that produced them.
+
+``torch.distributed`` is plumbing only; all path arithmetic is in the HIP kernels.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard of the global path range for ``rank``: ``(path_begin, n_paths)``.
+    Shards are ``ceil(N / world)`` long (the last ones shorter or empty); they tile ``[0, N)``."""
+    if world <= 0 or not (0 <= rank < world) or n_total < 0:
+        raise ValueError("bad shard arguments")
+    per = -(-n_total // world)
+    begin = min(rank * per, n_total)
+    return begin, min(per, n_total - begin)
+
+
+def is_active() -> bool:
+    """True when a torch.distributed process group with more than one rank is initialised."""
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return False
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _comm_device():
+    import torch
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+@dataclass
+class ReducedCounts:
+    success: int
+    paths: int
+    wr_obs_counts: np.ndarray   # [ry]
+    ruin_year_bins: np.ndarray  # [ry + 2]
+
+    @property
+    def success_probability_pct(self) -> float:
+        return float(np.float64(self.success) / np.float64(self.paths) * 100.0) if self.paths else 0.0
+
+
+def pack_counts(counters, wr_obs_counts, ruin_year_bins) -> np.ndarray:
+    return np.concatenate([np.asarray(counters, dtype=np.int64), np.asarray(wr_obs_counts, dtype=np.int64),
+                           np.asarray(ruin_year_bins, dtype=np.int64)])
+
+
+def unpack_counts(vec: np.ndarray, retirement_years: int) -> ReducedCounts:
+    ry = int(retirement_years)
+    assert vec.shape[0] == 2 + ry + ry + 2
+    return ReducedCounts(int(vec[0]), int(vec[1]), vec[2:2 + ry].copy(), vec[2 + ry:].copy())
+
+
+def all_reduce_sum_(tensor) -> None:
+    """In-place sum over ranks (the path's single exchange step)."""
+    import torch.distributed as dist
+
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+
+
+def all_reduce_minmax_(minmax) -> None:
+    """In-place: ``minmax[0]`` = min over ranks, ``minmax[1]`` = max over ranks (histogram range)."""
+    import torch.distributed as dist
+
+    lo, hi = minmax[0:1].clone(), minmax[1:2].clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    minmax[0:1].copy_(lo)
+    minmax[1:2].copy_(hi)
+
+
+LocalRunner = Callable[[int, int], Dict[str, np.ndarray]]
+"""``runner(path_begin, n_paths) -> {"counters", "wr_obs_counts", "ruin_year_bins"}`` for one shard."""
+
+
+def run_sharded_counts(n_total: int, retirement_years: int, local_runner: LocalRunner) -> ReducedCounts:
+    """Every rank simulates its shard with ``local_runner`` and the counter vectors are summed with a
+    single all-reduce; every rank returns the same global ``ReducedCounts``."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = (dist.get_rank(), dist.get_world_size()) if is_active() else (0, 1)
+    begin, count = shard_range(int(n_total), rank, world)
+    ry = int(retirement_years)
+    if count > 0:
+        r = local_runner(begin, count)
+        vec = pack_counts(r["counters"], r["wr_obs_counts"], r["ruin_year_bins"])
+    else:
+        vec = np.zeros(2 + ry + ry + 2, dtype=np.int64)
+    if world > 1:
+        t = torch.as_tensor(vec, device=_comm_device())
+        all_reduce_sum_(t)
+        vec = t.cpu().numpy()
+    return unpack_counts(vec, ry)
+
+
+def gpu_count_runner(params, seed: int, stream_id: int, working_months: int, device: Optional[int] = None) -> LocalRunner:
+    """The product's local runner: count-only HIP kernel over the shard (no per-path HBM traffic)."""
+    from . import engine as E
+
+    def run(path_begin: int, n_paths: int) -> Dict[str, np.ndarray]:
+        import torch
+
+        dev = torch.cuda.current_device() if device is None else device
+        batch = E.DeviceBatch(params, working_months, n_paths, want="count", device=dev)
+        batch.launch(seed, stream_id, path_begin)
+        return {"counters": batch.counters.cpu().numpy(), "wr_obs_counts": batch.wr_obs_counts.cpu().numpy(),
+                "ruin_year_bins": batch.ruin_year_bins.cpu().numpy()}
+
+    return run

@@ -26,6 +26,7 @@ import pandas as pd
 
 from . import _native as N
 from . import aggregation as A
+from . import distributed as D
 from . import engine as E
 from ._logging import logger
 from .config import Config
@@ -340,6 +341,15 @@ class RetirementMonteCarloSimulator:
         """Success % of a batch from the count-only kernel (no per-path HBM traffic).  Equals
         ``_success_probability(run_monte_carlo_simulations(...)[0])`` bit-for-bit: count/n*100."""
         n = int(num_simulations)
+        if D.is_active():
+            # one process per GPU: each rank simulates its shard of [0, n), counts are summed with a
+            # single all-reduce, every rank sees the same probability (and replays the same search)
+            params = self._current_params()
+            red = D.run_sharded_counts(
+                n, params.retirement_years,
+                D.gpu_count_runner(params, self._engine_seed, self._stream_id, int(working_months)),
+            )
+            return red.success_probability_pct
         batch = E.DeviceBatch(self._current_params(), int(working_months), n, want="count", device=self.device)
         batch.launch(self._engine_seed, self._stream_id, 0)
         ok = int(batch.counters[N.MCR_CTR_SUCCESS].item())

@@ -1,0 +1,73 @@
+"""N > 1 path of the engine on CPU: world_size-2 (and 3) gloo process groups.  Shards tile the
+global path range, the reduced counters equal a single-process run of the whole range, every
+rank ends with the same numbers."""
+
+from __future__ import annotations
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from monte_carlo_retirement_amd import Config, params_from_config
+from monte_carlo_retirement_amd import distributed as D
+
+
+def test_shard_range_tiles_the_path_range():
+    for n in (0, 1, 7, 64, 1000, 10**8 + 3):
+        for world in (1, 2, 3, 8):
+            shards = [D.shard_range(n, r, world) for r in range(world)]
+            assert sum(c for _, c in shards) == n
+            pos = 0
+            for b, c in shards:
+                assert b == pos or c == 0
+                pos += c
+            assert max(c for _, c in shards) - min(c for _, c in shards if True) <= -(-n // world)
+    with pytest.raises(ValueError):
+        D.shard_range(10, 2, 2)
+
+
+def test_pack_unpack_roundtrip():
+    v = D.pack_counts([5, 9], np.arange(3), np.arange(5) * 2)
+    r = D.unpack_counts(v, 3)
+    assert (r.success, r.paths) == (5, 9) and r.wr_obs_counts.tolist() == [0, 1, 2] and r.ruin_year_bins.tolist() == [0, 2, 4, 6, 8]
+    assert r.success_probability_pct == pytest.approx(5 / 9 * 100)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 301), (3, 64)])
+def test_sharded_counts_equal_single_process(tmp_path, oracle, world, n_total):
+    wm = 30
+    out = str(tmp_path / "res")
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                   WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_worker.py"), out, str(n_total), str(wm)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        stdout, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, stdout.decode()[-2000:]
+    res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
+        cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3))
+    whole = oracle.run_batch(params_from_config(cfg), 777, 1, 0, n_total, wm, want_summary=False, want_trajectories=False)
+    covered = sorted((b, c) for r in res for b, c in r["shards"])
+    assert sum(c for _, c in covered) == n_total and covered[0][0] == 0
+    for r in res:
+        assert r["active"] and r["world"] == world
+        assert r["success"] == int(whole["counters"][0]) and r["paths"] == n_total
+        assert r["wr"] == whole["wr_obs_counts"].tolist() and r["ruin"] == whole["ruin_year_bins"].tolist()
+        assert r["prob"] == res[0]["prob"]
+        assert r["minmax"] == [10.0, 100.0 * world]
