@@ -225,3 +225,30 @@ def test_full_search_matches_reference(idx):
     # the count-only probe equals the full run's success probability bit-for-bit
     full = sim._success_probability(sim.run_monte_carlo_simulations(months, sim.params_model.num_simulations_search)[0])
     assert full == prob
+
+
+def test_integration_md_ctypes_stub_runs_verbatim():
+    """the ctypes stub a reference maintainer would paste is executed as written
+    (against an object with the reference simulator's attributes) and agrees with the drop-in class."""
+    import os
+    import re
+
+    from conftest import REPO
+    from monte_carlo_retirement_amd import _native as N
+
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    code = re.findall(r"```python\n(.*?)```", text, flags=re.S)[1]
+    code = code.replace("/path/to/monte_carlo_retirement_amd/csrc/libmcr_hip.so", N.library_path())
+    ns: dict = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = load_golden("paths_injected.json")[3]
+    sim = RetirementMonteCarloSimulator(Config(**g["cfg"]), main_seed_override=g["seed"])
+    sim.use_final_seeds()
+    res = ns["run_paths_on_gpu"](sim, g["working_months"], g["n_paths"])
+    assert len(res) == g["n_paths"]
+    for got, exp in zip(res, g["results"]):
+        assert got["Success"] == exp["Success"]
+        for k in ("Start Balance", "Final Balance", "Inflation At Retirement", "First Year Real Gross Withdrawal"):
+            assert got[k] == pytest.approx(exp[k], rel=1e-9, abs=1e-6)
+        np.testing.assert_allclose(got["Trajectory"], exp["Trajectory"], rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(got["WithdrawalRateTrajectory"], exp["WithdrawalRateTrajectory"], rtol=1e-9, equal_nan=True)
