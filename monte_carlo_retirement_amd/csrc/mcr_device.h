@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/mcr.h"
+#include "mcr_math.h"
 
 namespace mcr {
 
@@ -75,26 +76,27 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 //   u = (x + 0.5) * 2^-32 in (0,1);  (z0, z1) = sqrt(-2 ln u0) (cos, sin)(2 pi u1);
 //   z2 = sqrt(-2 ln u2) cos(2 pi u3);  equity = z0, inflation = rho z0 + rho_c z1, premium = z2.
 __device__ __forceinline__ void shock_row(uint64_t seed, uint32_t stream_id, uint64_t path,
-                                          uint32_t month, double rho, double rho_c, double& z_eq,
-                                          double& z_inf, double& z_prem) {
+                                          uint32_t month, double rho, double rho_c, const double* tab,
+                                          double& z_eq, double& z_inf, double& z_prem) {
     uint32_t x[4];
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), month, stream_id, (uint32_t)seed,
                   (uint32_t)(seed >> 32), x);
-    constexpr double S = 2.3283064365386962890625e-10;  // 2^-32
-    const double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
-    const double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;
-    const double r0 = sqrt(-2.0 * log(u0));
-    const double r1 = sqrt(-2.0 * log(u2));
-    double s, c;
-    sincospi(2.0 * u1, &s, &c);
+    // radius and angle are taken straight from the Philox integers (mcr_math.h)
+    const double r0 = fsqrt(neg2_log_u32(x[0], tab));
+    const double r1 = fsqrt(neg2_log_u32(x[2], tab));
+    double s, c, s_unused, c2;
+    sincos_u32<true>(x[1], tab, s, c);
+    sincos_u32<false>(x[3], tab, s_unused, c2);
     const double z0 = r0 * c, z1 = r0 * s;
     z_eq = z0;
     z_inf = rho * z0 + rho_c * z1;
-    z_prem = r1 * cospi(2.0 * u3);
+    z_prem = r1 * c2;
 }
 
 // _monthly_gross_from_shock (:468-474) with a = mu_log/12 and b = sigma_log/sqrt(12) precomputed.
-__device__ __forceinline__ double monthly_gross(double a, double b, double z) { return exp(a + b * z); }
+__device__ __forceinline__ double monthly_gross(double a, double b, double z, const double* tab) {
+    return fexp(a + b * z, tab);
+}
 
 // _net_liquidation_value (:256-272); rate = realized rate if that system applies else 0.0.
 __device__ __forceinline__ double net_liquidation_value(double bal, double cb, double rate) {
@@ -107,10 +109,11 @@ __device__ __forceinline__ double net_liquidation_value(double bal, double cb, d
 __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
                                          double& gross_out, double& net_out) {
     const bool skip = (bal <= kEps) || (net_target <= 0.0);              // :218
-    const double gain_fraction = fmax(0.0, bal - cb) / bal;              // :221
+    const double inv_bal = recip_nr(bal);                                // shared by the two divisions by bal
+    const double gain_fraction = div_by(fmax(0.0, bal - cb), bal, inv_bal);  // :221
     const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
-    const double gross = fmin(net_target / net_fraction, bal);           // :228-231
-    const double fraction_sold = fmin(1.0, gross / bal);                 // :233
+    const double gross = fmin(fdiv(net_target, net_fraction), bal);      // :228-231
+    const double fraction_sold = fmin(1.0, div_by(gross, bal, inv_bal)); // :233
     const double basis_removed = fmin(cb, cb * fraction_sold);           // :234
     const double taxable_gain = fmax(0.0, gross - basis_removed);        // :235
     const double tax_paid = taxable_gain * rate;                         // :236-240
@@ -139,11 +142,12 @@ __device__ __forceinline__ void rebalance(const DevParams& P, double& b1, double
     const double drift = sell1 ? drift1 : drift2;
     const double alloc_s = sell1 ? P.alloc1 : P.alloc2;            // the SOLD asset's own weight (:309,:337)
     const double rate_s = sell1 ? P.real_rate1 : P.real_rate2;
-    const double gain_fraction = fmax(0.0, bs - cs) / bs;          // :301 / :329
+    const double inv_bs = recip_nr(bs);                            // shared by the two divisions by bs
+    const double gain_fraction = div_by(fmax(0.0, bs - cs), bs, inv_bs);  // :301 / :329
     const double tax_per_dollar = gain_fraction * rate_s;          // :302-306
     const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
-    const double gross_sale = fmin(bs, drift / denom);             // :311
-    const double fraction_sold = gross_sale / bs;                  // :312
+    const double gross_sale = fmin(bs, fdiv(drift, denom));        // :311
+    const double fraction_sold = div_by(gross_sale, bs, inv_bs);   // :312
     const double basis_removed = fmin(cs, cs * fraction_sold);     // :313
     const double taxable_gain = fmax(0.0, gross_sale - basis_removed);  // :314
     const double tax_paid = taxable_gain * rate_s;                 // :315-319
@@ -179,7 +183,7 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, double& b1
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
         if (cap > kEps && pay > 0.0) {                                // :408
-            const double share1 = cap1 / cap;                         // :409
+            const double share1 = fdiv(cap1, cap);                    // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
             withdraw(b1, c1, pay * share1, P.real_rate1, g, net1);    // :411-419
@@ -192,12 +196,12 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, double& b1
 }
 
 // Market step shared by both phases (:522-538 and :695-714).
-__device__ __forceinline__ void market_step(const DevParams& P, double z_eq, double z_inf,
-                                            double z_prem, double& b1, double& b2, double& gacc1,
-                                            double& gacc2, double& infl) {
-    const double g1 = monthly_gross(P.a1, P.b1, z_eq);
-    const double ginf = monthly_gross(P.ainf, P.binf, z_inf);
-    const double gprem = monthly_gross(P.aprem, P.bprem, z_prem);
+__device__ __forceinline__ void market_step(const DevParams& P, const double* tab, double z_eq,
+                                            double z_inf, double z_prem, double& b1, double& b2,
+                                            double& gacc1, double& gacc2, double& infl) {
+    const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab);
+    const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab);
+    const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab);
     const double g2 = ginf * gprem;   // :532
     gacc1 += b1 * (g1 - 1.0);         // :534
     gacc2 += b2 * (g2 - 1.0);         // :535

@@ -41,8 +41,11 @@ __device__ __forceinline__ double nan_f64() { return __longlong_as_double(0x7ff8
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const KernelIO io) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // LDS: [n_lock_slots][kBlock] doubles (frozen nominal stream amounts), then block counters
-    double* lock_lds = reinterpret_cast<double*>(smem_raw);
+    // LDS: math tables (mcr_math.h), [n_lock_slots][kBlock] doubles (frozen nominal stream amounts),
+    // then block counters
+    double* tab = reinterpret_cast<double*>(smem_raw);
+    load_math_tables(tab, threadIdx.x, kBlock);
+    double* lock_lds = tab + kTabDoubles;
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
     // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram
     const int ry = P.retirement_years;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
             const int r = row < P.shock_rows - 1 ? row : P.shock_rows - 1;  // :692
             ze = inj[3 * r + 0]; zi = inj[3 * r + 1]; zp = inj[3 * r + 2];
         } else {
-            shock_row(io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, ze, zi, zp);
+            shock_row(io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, tab, ze, zi, zp);
         }
     };
 
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
         if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) contrib *= P.contrib_growth_factor;  // :514-517
         double ze, zi, zp;
         shocks(m - 1, ze, zi, zp);                                     // :519-520
-        market_step(P, ze, zi, zp, b1, b2, gacc1, gacc2, infl);        // :522-538
+        market_step(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);   // :522-538
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
                 if (!stop) {
                     double ze, zi, zp;
                     shocks(wm + rmi, ze, zi, zp);                      // :692-693
-                    market_step(P, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
+                    market_step(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
                     if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
                         b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
                         yfail = true; stop = true;
@@ -162,14 +165,14 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmax(0.0, fmin(need, cap));                 // :739-742
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
-                    const double prop1 = cap > kEps ? cap1 / cap : P.alloc1;          // :750-754
+                    const double prop1 = cap > kEps ? fdiv(cap1, cap) : P.alloc1;     // :750-754
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
                     withdraw(b1, c1, target * prop1, P.real_rate1, gw1, nw1);         // :757-765
                     tg1 += gw1;                                                       // :766
                     withdraw(b2, c2, target * prop2, P.real_rate2, gw2, nw2);         // :768-776
                     tg2 += gw2;                                                       // :777
-                    if (kSummary) treal += (gw1 + gw2) * infl_ret / fmax(price, kEps);  // :778-782
+                    if (kSummary) treal += fdiv((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
                     rebalance(P, b1, c1, b2, c2);                                     // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
@@ -263,6 +266,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
 // Device unit functions exposed for the reference's helper-level tests
 // ---------------------------------------------------------------------------------------------
 __global__ void helper_kernel(int which, const DevParams P, const double* in, double* out, int64_t n) {
+    __shared__ double tab[kTabDoubles];
+    load_math_tables(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     switch (which) {
@@ -297,7 +303,7 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
         }
         case MCR_HELPER_MONTHLY_GROSS: {
             const double* x = in + 3 * i;
-            out[i] = monthly_gross(x[0] / (double)kMPY, x[1] / sqrt((double)kMPY), x[2]);  // :473
+            out[i] = monthly_gross(x[0] / (double)kMPY, x[1] / sqrt((double)kMPY), x[2], tab);  // :473
             break;
         }
         default: break;
@@ -307,13 +313,16 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
 // _draw_shock_path (:452-466): out[n_paths][n_months][3]
 __global__ void shocks_kernel(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                               int32_t n_months, double rho, double rho_c, double* out) {
+    __shared__ double tab[kTabDoubles];
+    load_math_tables(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = n_paths * (uint64_t)n_months;
     if (idx >= total) return;
     const uint64_t p = idx / (uint64_t)n_months;
     const uint32_t m = (uint32_t)(idx % (uint64_t)n_months);
     double ze, zi, zp;
-    shock_row(seed, stream_id, path_begin + p, m, rho, rho_c, ze, zi, zp);
+    shock_row(seed, stream_id, path_begin + p, m, rho, rho_c, tab, ze, zi, zp);
     out[3 * idx + 0] = ze; out[3 * idx + 1] = zi; out[3 * idx + 2] = zp;
 }
 
@@ -436,7 +445,7 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
 }
 
 static size_t path_kernel_lds_bytes(const DevParams& d) {
-    return (size_t)d.n_lock_slots * kBlock * sizeof(double) +
+    return (size_t)kMathTabBytes + (size_t)d.n_lock_slots * kBlock * sizeof(double) +
            (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1)) * sizeof(unsigned int);
 }
 

@@ -1,0 +1,111 @@
+// mcr_math.h — fp64 math specialised for the path kernel's operand domains (gfx950).
+//
+// The generic device libm (OCML) pays for ranges and special cases this kernel never sees
+// (denormals, overflow, NaN, huge trig arguments).  Measured on MI355X one fp64 add/mul/fma
+// costs one VALU issue slot, v_rcp/rsq_f64 ~3.5 slots, an IEEE fp64 division ~13.5 slots, and
+// the RNG + growth factors alone were ~45 % of the 725 VALU instructions per path-month.
+//
+//   fdiv / recip_nr   the IEEE division sequence without v_div_scale/v_div_fixup: bit-identical to
+//                     `a / b` whenever no exponent scaling is needed (balances live in 1e-6..1e15);
+//                     the Newton reciprocal is shared by quotients with the same divisor.
+//   fexp              exp(x), |x| < 700: 2^(k/64) table (LDS) + degree-6 polynomial, <= ~1.5 ulp.
+//   neg2_log_u32      -2 ln((x+0.5) 2^-32) straight from the Philox integer: 128-entry table of
+//                     (1/c, -2 ln c) + degree-6 series, absolute error ~1e-17 (Box-Muller radius^2).
+//   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 2 corrections.
+//   sincos_u32        sin/cos(2 pi (x+0.5) 2^-32): top 8 bits index a 256-entry (sin,cos) table of
+//                     bin centres, the low 24 bits give |delta| <= pi/256, rotated with short series.
+// Tables are correctly rounded (tools/gen_tables.py) and staged in LDS once per workgroup.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mcr_tables.h"
+
+namespace mcr {
+
+constexpr int kMathTabBytes = kTabDoubles * (int)sizeof(double);  // 6656 B of LDS
+
+// every thread of a kBlockThreads-wide workgroup calls this once; caller syncs afterwards
+__device__ __forceinline__ void load_math_tables(double* lds_tab, int tid, int nthreads) {
+    for (int i = tid; i < kTabDoubles; i += nthreads) lds_tab[i] = kMathTab[i];
+}
+
+// 1/b to full precision: v_rcp_f64 seed + two Newton steps (the core of LLVM's IEEE fdiv lowering)
+__device__ __forceinline__ double recip_nr(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+// a / b given y = recip_nr(b): quotient estimate + one residual correction (== v_div_fmas unscaled)
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+__device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr(b)); }
+
+__device__ __forceinline__ double fexp(double x, const double* tab) {
+    const double kf = __builtin_rint(x * k64OverLn2);
+    double r = __builtin_fma(-kf, kLn2Over64Hi, x);
+    r = __builtin_fma(-kf, kLn2Over64Lo, r);
+    const int k = (int)kf;
+    const double t = tab[kTabExp2 + (k & 63)];
+    // e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24 + r^3/120 + r^4/720), |r| <= ln2/128
+    double p = __builtin_fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = __builtin_fma(r, p, 1.0 / 24.0);
+    p = __builtin_fma(r, p, 1.0 / 6.0);
+    p = __builtin_fma(r, p, 0.5);
+    p = __builtin_fma(r * r, p, r);
+    return __builtin_ldexp(__builtin_fma(t, p, t), k >> 6);
+}
+
+__device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab) {
+    const double d = __builtin_fma((double)x, 2.0, 1.0);  // 2x+1, exact, in [1, 2^33)
+    const uint64_t bits = (uint64_t)__double_as_longlong(d);
+    const uint32_t hi = (uint32_t)(bits >> 32);
+    const int i = (int)((hi >> 13) & 127u);               // top 7 fraction bits
+    const double m = __longlong_as_double((long long)((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+    const double inv_c = tab[kTabLog + 2 * i], w_i = tab[kTabLog + 2 * i + 1];
+    const double r = __builtin_fma(m, inv_c, -1.0);       // |r| <= 2^-8
+    // -2 ln(1+r) = -2r + r^2 (1 - 2r/3 + r^2/2 - 2r^3/5 + r^4/3)
+    double p = __builtin_fma(r, 1.0 / 3.0, -0.4);
+    p = __builtin_fma(r, p, 0.5);
+    p = __builtin_fma(r, p, -2.0 / 3.0);
+    p = __builtin_fma(r, p, 1.0);
+    const double q = __builtin_fma(r * r, p, -2.0 * r);
+    const double e = (double)((int)(hi >> 20) - (1023 + 33));  // u = (2x+1) 2^-33
+    const double w = __builtin_fma(e, kM2Ln2Hi, w_i);     // e * hi is exact (21 trailing zero bits)
+    return w + __builtin_fma(e, kM2Ln2Lo, q);
+}
+
+__device__ __forceinline__ double fsqrt(double w) {  // w normal, > 0
+    const double y = __builtin_amdgcn_rsq(w);
+    double g = w * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, w);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, w);
+    return __builtin_fma(d, h, g);
+}
+
+template <bool WANT_SIN>
+__device__ __forceinline__ void sincos_u32(uint32_t x, const double* tab, double& s, double& c) {
+    const int k = (int)(x >> 24);
+    const double S = tab[kTabSinCos + 2 * k], C = tab[kTabSinCos + 2 * k + 1];
+    const double dl = __builtin_fma((double)(x & 0x00FFFFFFu), kAngleScale, kAngleBias);  // |dl| <= pi/256
+    const double d2 = dl * dl;
+    const double sd = __builtin_fma(dl * d2, __builtin_fma(d2, 1.0 / 120.0, -1.0 / 6.0), dl);  // sin(dl)
+    double cp = __builtin_fma(d2, -1.0 / 720.0, 1.0 / 24.0);
+    cp = __builtin_fma(d2, cp, -0.5);
+    const double cd = d2 * cp;                                                               // cos(dl) - 1
+    c = C + __builtin_fma(C, cd, -(S * sd));
+    if (WANT_SIN) s = S + __builtin_fma(S, cd, C * sd);
+}
+
+}  // namespace mcr

@@ -1,0 +1,88 @@
+// Per-instruction issue cost on gfx950: each kernel runs a long unrolled stream of ONE VALU
+// instruction kind (8 independent chains per lane), 4 waves per SIMD on every CU.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_cost valu_cost.hip && ./valu_cost
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <string>
+
+#define ITERS 2048
+#define CHAINS 8
+
+#define KERNEL(NAME, TYPE, INIT, BODY)                                                  \
+    __global__ __launch_bounds__(256) void k_##NAME(TYPE* out, TYPE seed) {             \
+        TYPE v[CHAINS];                                                                 \
+        _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) v[c] = INIT;                 \
+        for (int i = 0; i < ITERS; ++i) {                                               \
+            _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) { TYPE& x = v[c]; BODY; } \
+        }                                                                               \
+        TYPE acc = v[0];                                                                \
+        _Pragma("unroll") for (int c = 1; c < CHAINS; ++c) acc = acc + v[c];            \
+        if (acc == (TYPE)123456789) out[0] = acc;                                       \
+    }
+
+#define ASM1(op) asm volatile(op " %0, %0" : "+v"(x))
+#define ASM2(op) asm volatile(op " %0, %0, %1" : "+v"(x) : "v"(seed))
+#define ASM3(op) asm volatile(op " %0, %0, %1, %0" : "+v"(x) : "v"(seed))
+
+KERNEL(fma_f64, double, seed + threadIdx.x + c, ASM3("v_fma_f64"))
+KERNEL(mul_f64, double, seed + threadIdx.x + c, ASM2("v_mul_f64"))
+KERNEL(add_f64, double, seed + threadIdx.x + c, ASM2("v_add_f64"))
+KERNEL(max_f64, double, seed + threadIdx.x + c, ASM2("v_max_f64"))
+KERNEL(rcp_f64, double, seed + threadIdx.x + c, ASM1("v_rcp_f64"))
+KERNEL(rsq_f64, double, seed + threadIdx.x + c, ASM1("v_rsq_f64"))
+KERNEL(sqrt_f64, double, seed + threadIdx.x + c, ASM1("v_sqrt_f64"))
+KERNEL(ldexp_f64, double, seed + threadIdx.x + c, asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(x)))
+KERNEL(rndne_f64, double, seed + threadIdx.x + c, ASM1("v_rndne_f64"))
+KERNEL(frexp_mant_f64, double, seed + threadIdx.x + c, ASM1("v_frexp_mant_f64"))
+KERNEL(div_scale_f64, double, seed + threadIdx.x + c, asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(x) : "v"(seed) : "vcc"))
+KERNEL(div_fixup_f64, double, seed + threadIdx.x + c, asm volatile("v_div_fixup_f64 %0, %0, %1, %0" : "+v"(x) : "v"(seed)))
+KERNEL(div_fmas_f64, double, seed + threadIdx.x + c, asm volatile("v_div_fmas_f64 %0, %0, %1, %0" : "+v"(x) : "v"(seed) : "vcc"))
+KERNEL(fma_f32, float, seed + threadIdx.x + c, ASM3("v_fma_f32"))
+KERNEL(add_u32, uint32_t, seed + threadIdx.x + c, ASM2("v_add_u32"))
+KERNEL(xor_b32, uint32_t, seed + threadIdx.x + c, ASM2("v_xor_b32"))
+KERNEL(mul_lo_u32, uint32_t, seed + threadIdx.x + c, ASM2("v_mul_lo_u32"))
+KERNEL(mul_hi_u32, uint32_t, seed + threadIdx.x + c, ASM2("v_mul_hi_u32"))
+KERNEL(cndmask_b32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(seed) : "vcc"))
+KERNEL(mad_u64_u32, uint64_t, seed + threadIdx.x + c, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x) : "v"((uint32_t)seed), "v"((uint32_t)threadIdx.x) : "vcc"))
+KERNEL(cvt_f64_u32, double, seed + threadIdx.x + c, asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(x) : "v"((uint32_t)threadIdx.x)))
+KERNEL(cmp_f64, double, seed + threadIdx.x + c, asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(x), "v"(seed) : "vcc"))
+KERNEL(mov_b32, uint32_t, seed + threadIdx.x + c, asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(seed)))
+
+template <typename T>
+static void run(const char* name, void (*k)(T*, T), T seed) {
+    T* d;
+    hipMalloc(&d, 64);
+    const int blocks = 256 * 4;  // 4 workgroups of 256 per CU = 4 waves per SIMD
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, seed);
+    hipDeviceSynchronize();
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e30f;
+    for (int r = 0; r < 5; ++r) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, seed);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    // wave-instructions per SIMD = 4 waves * ITERS * CHAINS; cycles at 2.4 GHz nominal
+    const double insts_per_simd = 4.0 * ITERS * CHAINS;
+    const double ns = best * 1e6;
+    printf("%-16s %8.3f ms  %6.2f ns/wave-inst/SIMD  ~%5.2f cycles @2.4GHz\n", name, best, ns / insts_per_simd, ns / insts_per_simd * 2.4);
+    hipFree(d);
+}
+
+int main() {
+#define RUN(NAME, TYPE, SEED) run<TYPE>(#NAME, k_##NAME, (TYPE)SEED)
+    RUN(fma_f64, double, 1.0000001); RUN(mul_f64, double, 1.0000001); RUN(add_f64, double, 1e-9); RUN(max_f64, double, 1.5);
+    RUN(rcp_f64, double, 1.5); RUN(rsq_f64, double, 1.5); RUN(sqrt_f64, double, 1.5); RUN(ldexp_f64, double, 1e-300);
+    RUN(rndne_f64, double, 1.5); RUN(frexp_mant_f64, double, 1.5);
+    RUN(div_scale_f64, double, 1.5); RUN(div_fixup_f64, double, 1.5); RUN(div_fmas_f64, double, 1.0000001);
+    RUN(fma_f32, float, 1.0000001f); RUN(add_u32, uint32_t, 3); RUN(xor_b32, uint32_t, 3); RUN(mul_lo_u32, uint32_t, 3);
+    RUN(mul_hi_u32, uint32_t, 3); RUN(cndmask_b32, uint32_t, 3); RUN(mad_u64_u32, uint64_t, 3); RUN(cvt_f64_u32, double, 1.0);
+    RUN(cmp_f64, double, 1.0); RUN(mov_b32, uint32_t, 3);
+    return 0;
+}
