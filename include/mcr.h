@@ -184,9 +184,10 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
  * NaNs skipped): for each of n_rows rows of `n` doubles at rows[r*row_stride + i], writes
  * out[r*n_q + j] = quantile(q[j]) (NaN for an all-NaN row) and, if counts != NULL,
  * counts[r] = number of non-NaN entries.  rows/out/counts are DEVICE pointers; q is HOST.
- * scratch: device buffer of mcr_row_quantiles_scratch_bytes(n_rows, n_q) bytes.
+ * scratch: device buffer of mcr_row_quantiles_scratch_bytes(n_rows, n_q, n) bytes (selection state,
+ * digit histograms and a per-row candidate buffer of n/64 + 4096 keys); 0 = unsupported shape.
  */
-int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q);
+int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n);
 int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n,
                       const double* q, int32_t n_q, double* out, uint64_t* counts,
                       void* scratch, int device, void* hip_stream);

@@ -161,7 +161,7 @@ def _declare(lib: C.CDLL) -> None:
         C.c_int, P(McrParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
     ]
     lib.mcr_row_quantiles_scratch_bytes.restype = C.c_int64
-    lib.mcr_row_quantiles_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.mcr_row_quantiles_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int64]
     lib.mcr_row_quantiles.restype = C.c_int
     lib.mcr_row_quantiles.argtypes = [
         C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,

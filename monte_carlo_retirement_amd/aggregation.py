@@ -41,7 +41,7 @@ def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0) -> Tuple[n
     dev = rows.device
     out = torch.empty((n_rows, len(q)), dtype=torch.float64, device=dev)
     counts = torch.zeros(n_rows, dtype=torch.int64, device=dev)
-    nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q)))
+    nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q), int(n)))
     if nbytes <= 0:
         raise ValueError("unsupported number of rows / quantiles")
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -33,6 +33,8 @@ struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
     double gamma[kRqMaxQ];               // interpolation weight of quantile j
     int group_of[kRqMaxT];
     int n_targets, n_groups;
+    unsigned int cand_count;             // keys appended to the candidate buffer in pass 3
+    unsigned int overflow;               // 1 if they did not fit (row falls back to full passes)
 };
 
 struct RqArgs {
@@ -49,33 +51,118 @@ __device__ __forceinline__ double value_of(unsigned long long k) {
     return __longlong_as_double((long long)b);
 }
 
+// Wave-aggregated LDS histogram update.  In the first digit passes nearly every lane of a wave hits
+// the same bin (balances of one year share sign/exponent), and 64 same-address LDS atomics serialise;
+// so the two most common (group, digit) keys of the wave are peeled with a ballot + one atomic each,
+// and only the remaining lanes issue individual atomics.
+__device__ __forceinline__ void hist_add_aggregated(unsigned int* lh, bool active, unsigned int key) {
+    unsigned long long todo = __ballot(active);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (todo == 0ull) return;
+        const int lead = __ffsll((long long)todo) - 1;
+        const unsigned int k0 = (unsigned int)__shfl((int)key, lead, 64);
+        const unsigned long long same = __ballot(active && key == k0) & todo;
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&lh[k0], (unsigned int)__popcll(same));
+        todo &= ~same;
+    }
+    if (active && ((todo >> (threadIdx.x & 63)) & 1ull)) atomicAdd(&lh[key], 1u);
+}
+
 // One histogram pass: hist[row][group][digit] += #elements whose key has the group's prefix.
-template <bool FIRST>
+// PASS3 additionally compacts the matching keys of the row into cand[row][..] (the later passes
+// then stream only those).  16-byte loads (two doubles per lane) when the row allows it.
+template <bool FIRST, bool COMPACT>
 __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restrict__ rows, int64_t row_stride,
-                                                          int64_t n, int pass, RqRow* st, unsigned int* hist) {
-    __shared__ unsigned int lh[kRqMaxT * 256];
+                                                          int64_t n, int pass, RqRow* st, unsigned int* hist,
+                                                          unsigned long long* cand, unsigned int cand_cap,
+                                                          int only_overflowed) {
+    extern __shared__ __align__(16) unsigned int lh[];  // [max groups of this call][256], sized by the host
     __shared__ unsigned long long lpref[kRqMaxT];
     __shared__ unsigned int lnan;
+    constexpr int kStage = 1024;  // candidate keys staged per workgroup before ONE global slot reservation
+    __shared__ unsigned long long stage[COMPACT ? kStage : 1];
+    __shared__ unsigned int stage_n, stage_base;
     const int row = blockIdx.y;
+    if (only_overflowed && !st[row].overflow) return;  // slow path only for rows whose candidates overflowed
     const int G = FIRST ? 1 : st[row].n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
-    if (threadIdx.x == 0) lnan = 0u;
+    if (threadIdx.x == 0) { lnan = 0u; stage_n = 0u; }
     __syncthreads();
     const double* r = rows + (int64_t)row * row_stride;
     const int shift_digit = 56 - 8 * pass;
     unsigned int my_nan = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kRqBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRqBlock) {
-        const double x = r[i];
-        if (x != x) { my_nan += FIRST ? 1u : 0u; continue; }
+    const bool vec2 = ((row_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+    const int64_t n_pairs = vec2 ? n / 2 : 0;
+    unsigned long long* crow = COMPACT ? cand + (size_t)row * cand_cap : nullptr;
+
+    auto consume = [&](double x, bool in_range) {
+        const bool isnan_x = x != x;
+        if (FIRST && in_range && isnan_x) ++my_nan;
         const unsigned long long k = key_of(x);
         const unsigned int digit = (unsigned int)(k >> shift_digit) & 0xFFu;
-        if (FIRST) {
-            atomicAdd(&lh[digit], 1u);
-        } else {
+        bool active = in_range && !isnan_x;
+        unsigned int key = digit;
+        if (!FIRST) {
             const unsigned long long hk = k >> (shift_digit + 8);
-            for (int g = 0; g < G; ++g)
-                if (hk == lpref[g]) atomicAdd(&lh[g * 256 + digit], 1u);
+            int g = -1;
+            for (int j = 0; j < G; ++j)
+                if (hk == lpref[j]) g = j;   // groups have distinct prefixes: at most one matches
+            active = active && g >= 0;
+            key = (unsigned int)(g < 0 ? 0 : g) * 256u + digit;
+        }
+        hist_add_aggregated(lh, active, key);
+        if (COMPACT) {  // wave-aggregated append of the matching keys into the workgroup's LDS stage
+            const unsigned long long m = __ballot(active);
+            if (m) {
+                const int lane = threadIdx.x & 63;
+                const int lead = __ffsll((long long)m) - 1;
+                unsigned int base = 0;
+                if (lane == lead) base = atomicAdd(&stage_n, (unsigned int)__popcll(m));
+                base = (unsigned int)__shfl((int)base, lead, 64);
+                if (active) {
+                    const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (slot < (unsigned int)kStage) {
+                        stage[slot] = k;
+                    } else {  // stage full (heavy ties): reserve a global slot directly
+                        const unsigned int gslot = atomicAdd(&st[row].cand_count, 1u);
+                        if (gslot < cand_cap) crow[gslot] = k;
+                    }
+                }
+            }
+        }
+    };
+
+    // main loop: every lane of a wave takes the same number of trips (the aggregation uses ballots)
+    const int64_t step = (int64_t)gridDim.x * kRqBlock;
+    if (vec2) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t* r2 = reinterpret_cast<const d2_t*>(r);
+        const int64_t trips = (n_pairs + step - 1) / step;
+        constexpr int kUnroll = 4;  // four 16-byte loads in flight per lane: HBM latency needs the bytes
+        for (int64_t t = 0; t < trips; t += kUnroll) {
+            d2_t v[kUnroll];
+            bool ok[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t i = (t + u) * step + (int64_t)blockIdx.x * kRqBlock + threadIdx.x;
+                ok[u] = i < n_pairs;
+                v[u] = ok[u] ? __builtin_nontemporal_load(&r2[i]) : d2_t{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                consume(v[u].x, ok[u]);
+                consume(v[u].y, ok[u]);
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0) consume(r[n - 1], threadIdx.x == 0);  // odd tail element
+    } else {
+        const int64_t trips = (n + step - 1) / step;
+        for (int64_t t = 0; t < trips; ++t) {
+            const int64_t i = t * step + (int64_t)blockIdx.x * kRqBlock + threadIdx.x;
+            const bool ok = i < n;
+            consume(ok ? r[i] : 0.0, ok);
         }
     }
     if (FIRST && my_nan) atomicAdd(&lnan, my_nan);
@@ -84,17 +171,64 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock)
         if (lh[k]) atomicAdd(&gh[k], lh[k]);
     if (FIRST && threadIdx.x == 0 && lnan) atomicAdd(&st[row].nan_count, (unsigned long long)lnan);
+    if (COMPACT) {  // flush the stage: one global reservation per workgroup, coalesced copy
+        const unsigned int cnt = stage_n < (unsigned int)kStage ? stage_n : (unsigned int)kStage;
+        if (threadIdx.x == 0) stage_base = cnt ? atomicAdd(&st[row].cand_count, cnt) : 0u;
+        __syncthreads();
+        for (unsigned int k = threadIdx.x; k < cnt; k += kRqBlock)
+            if (stage_base + k < cand_cap) crow[stage_base + k] = stage[k];
+    }
+}
+
+// Passes 4..7 over the compacted candidate keys of one row (one workgroup per row; the candidates
+// are a few thousand keys, L2-resident).  Rows whose candidates overflowed are left to the slow path.
+__global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow* st, unsigned int* hist,
+                                                               const unsigned long long* cand, unsigned int cand_cap) {
+    extern __shared__ __align__(16) unsigned int lh[];
+    __shared__ unsigned long long lpref[kRqMaxT];
+    const int row = blockIdx.y;
+    RqRow& S = st[row];
+    if (S.overflow) return;
+    const int G = S.n_groups;
+    for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
+    if (threadIdx.x < G) lpref[threadIdx.x] = S.prefix[threadIdx.x];
+    __syncthreads();
+    const unsigned int cnt = S.cand_count;
+    const unsigned long long* crow = cand + (size_t)row * cand_cap;
+    const int shift_digit = 56 - 8 * pass;
+    const unsigned int stride = gridDim.x * kRqBlock;
+    const unsigned int trips = (cnt + stride - 1) / stride;
+    for (unsigned int t = 0; t < trips; ++t) {
+        const unsigned int i = t * stride + blockIdx.x * kRqBlock + threadIdx.x;
+        const bool ok = i < cnt;
+        const unsigned long long k = ok ? crow[i] : 0ull;
+        const unsigned long long hk = k >> (shift_digit + 8);
+        int g = -1;
+        for (int j = 0; j < G; ++j)
+            if (hk == lpref[j]) g = j;
+        hist_add_aggregated(lh, ok && g >= 0, (unsigned int)(g < 0 ? 0 : g) * 256u + ((unsigned int)(k >> shift_digit) & 0xFFu));
+    }
+    __syncthreads();
+    unsigned int* gh = hist + (size_t)row * kRqMaxT * 256;
+    for (int k = threadIdx.x; k < G * 256; k += kRqBlock)
+        if (lh[k]) atomicAdd(&gh[k], lh[k]);
 }
 
 // Per row: advance every target by one digit, regroup, clear the histograms; after the last pass
 // interpolate (NumPy `linear`) and write the quantiles.
 __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow* st, unsigned int* hist,
-                                                    const RqArgs args, double* out, unsigned long long* counts) {
+                                                    const RqArgs args, double* out, unsigned long long* counts,
+                                                    unsigned int cand_cap) {
     __shared__ unsigned long long new_prefix[kRqMaxT];
+    extern __shared__ __align__(16) unsigned int sh[];  // this row's histograms, [n_groups][256]
     const int row = blockIdx.x;
     RqRow& S = st[row];
     unsigned int* gh = hist + (size_t)row * kRqMaxT * 256;
     const int t = threadIdx.x;
+    {
+        const int ng = pass == 0 ? 1 : S.n_groups;
+        for (int k = t; k < ng * 256; k += 64) sh[k] = gh[k];
+    }
     if (pass == 0 && t == 0) {
         const unsigned long long m = (unsigned long long)n - S.nan_count;
         S.n_valid = m;
@@ -121,7 +255,7 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
     const int nt = S.n_targets;
     if (t < nt) {
         const int g = S.group_of[t];
-        const unsigned int* h = gh + g * 256;
+        const unsigned int* h = sh + g * 256;
         unsigned long long rank = S.rank[t], cum = 0;
         int d = 0;
         for (; d < 255; ++d) {
@@ -147,6 +281,7 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
         S.n_groups = ng > 0 ? ng : 1;
     }
     for (int k = t; k < old_groups * 256; k += 64) gh[k] = 0u;  // ready for the next pass / call
+    if (pass == 3 && t == 0) S.overflow = S.cand_count > cand_cap ? 1u : 0u;
     __syncthreads();
     if (pass == 7) {
         if (t < nt) S.value[t] = value_of(new_prefix[t]);
@@ -171,7 +306,10 @@ __global__ void rq_init_kernel(RqRow* st, unsigned int* hist, int n_rows) {
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x)
         hist[k] = 0u;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_rows) { st[r].nan_count = 0ull; st[r].n_valid = 0ull; st[r].n_targets = 0; st[r].n_groups = 1; st[r].prefix[0] = 0ull; }
+    if (r < n_rows) {
+        st[r].nan_count = 0ull; st[r].n_valid = 0ull; st[r].n_targets = 0; st[r].n_groups = 1; st[r].prefix[0] = 0ull;
+        st[r].cand_count = 0u; st[r].overflow = 0u;
+    }
 }
 
 // ---- K2: successful-cohort min/max and equal-width histogram ------------------------------------
@@ -266,9 +404,12 @@ using namespace mcr;
 
 extern "C" {
 
-int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q) {
-    if (n_rows <= 0 || n_q <= 0 || n_q > kRqMaxQ) return 0;
-    return (int64_t)n_rows * (int64_t)(sizeof(RqRow) + (size_t)kRqMaxT * 256 * sizeof(unsigned int));
+static unsigned int rq_cand_cap(int64_t n) { return (unsigned int)(n / 64 + 4096); }
+
+int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n) {
+    if (n_rows <= 0 || n_q <= 0 || n_q > kRqMaxQ || n <= 0 || n >= ((int64_t)1 << 32)) return 0;
+    return (int64_t)n_rows * (int64_t)(sizeof(RqRow) + (size_t)kRqMaxT * 256 * sizeof(unsigned int) +
+                                      (size_t)rq_cand_cap(n) * sizeof(unsigned long long));
 }
 
 int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q,
@@ -283,20 +424,37 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     for (int j = 0; j < n_q; ++j)
         if (!(q[j] >= 0.0 && q[j] <= 1.0)) { set_error("quantile %d out of [0,1]", j); return MCR_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)hip_stream;
+    const unsigned int cap = rq_cand_cap(n);
     RqRow* st = (RqRow*)scratch;
     unsigned int* hist = (unsigned int*)((char*)scratch + (size_t)n_rows * sizeof(RqRow));
+    unsigned long long* cand = (unsigned long long*)((char*)hist + (size_t)n_rows * kRqMaxT * 256 * sizeof(unsigned int));
     RqArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
     hipLaunchKernelGGL(rq_init_kernel, dim3(grid_for((int64_t)n_rows * kRqMaxT * 256, 256, 1024)), dim3(256), 0, s, st, hist, n_rows);
-    int bx = grid_for(n, kRqBlock * 8, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
+    // each workgroup streams >= 16 elements per lane; ~4096 workgroups in flight fill the 256 CUs
+    int bx = grid_for(n, kRqBlock * 16, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
     if (bx < 1) bx = 1;
     const dim3 grid(bx, n_rows), block(kRqBlock);
+    // rows whose candidates overflowed (big ties, e.g. the all-equal t=0 row) re-stream alone: give each
+    // row a wide grid; workgroups of the other rows exit at once
+    const dim3 grid_slow(grid_for(n, kRqBlock * 16, 1024), n_rows);
+    unsigned long long* cnt = (unsigned long long*)counts;
+    const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);  // <= 2 targets per quantile
+    const size_t lds_first = 256 * sizeof(unsigned int);
     for (int pass = 0; pass < 8; ++pass) {
-        if (pass == 0) hipLaunchKernelGGL(rq_hist_kernel<true>, grid, block, 0, s, rows, row_stride, n, pass, st, hist);
-        else hipLaunchKernelGGL(rq_hist_kernel<false>, grid, block, 0, s, rows, row_stride, n, pass, st, hist);
-        hipLaunchKernelGGL(rq_scan_kernel, dim3(n_rows), dim3(64), 0, s, n, pass, st, hist, a, out, (unsigned long long*)counts);
+        if (pass == 0) {
+            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, st, hist, cand, cap, 0);
+        } else if (pass < 3) {
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, st, hist, cand, cap, 0);
+        } else if (pass == 3) {
+            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, st, hist, cand, cap, 0);
+        } else {
+            hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, n_rows), block, lds_groups, s, pass, st, hist, cand, cap);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, st, hist, cand, cap, 1);
+        }
+        hipLaunchKernelGGL(rq_scan_kernel, dim3(n_rows), dim3(64), lds_groups, s, n, pass, st, hist, a, out, cnt, cap);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "row quantile kernels");
