@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCR_ABI_VERSION 1
+#define MCR_ABI_VERSION 2
 #define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
 #define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */
@@ -39,6 +39,31 @@ extern "C" {
 /* Seed streams: replaces SeedSequence(main).spawn(2) (backend/simulation.py:147-151). */
 #define MCR_STREAM_SEARCH 0u
 #define MCR_STREAM_FINAL 1u
+
+/*
+ * Random stream of a batch.
+ *  MCR_RNG_PHILOX  the engine's native stream: Philox4x32-10, key = philox_seed, counter =
+ *                  (path_lo, path_hi, month, stream_id) -> Box-Muller (3 normals / month).
+ *  MCR_RNG_NUMPY   the REFERENCE's own stream, reproduced on the device: path i of the batch is
+ *                  child (stream_id, child_offset + i) of SeedSequence(main_seed) -> generate_state(1)
+ *                  -> default_rng(seed32) = PCG64 -> Generator.standard_normal (ziggurat), exactly
+ *                  what backend/simulation.py:148-149,195-197,457-458 executes through NumPy.
+ *                  `entropy` = main_seed as little-endian uint32 words; `child_offset` = the stream's
+ *                  SeedSequence.n_children_spawned when the reference would spawn this batch's seeds;
+ *                  `path_seeds` (optional) = explicit uint32 seed per path instead of the derivation
+ *                  (what _run_single_simulation_path(working_months, path_seed) receives).
+ */
+#define MCR_RNG_PHILOX 0u
+#define MCR_RNG_NUMPY 1u
+#define MCR_MAX_ENTROPY_WORDS 8
+typedef struct mcr_rng {
+    uint32_t kind;
+    uint32_t n_entropy_words;                /* 1..MCR_MAX_ENTROPY_WORDS (numpy) */
+    uint32_t entropy[MCR_MAX_ENTROPY_WORDS]; /* numpy: main_seed words, least significant first */
+    uint64_t philox_seed;                    /* philox key */
+    uint64_t child_offset;                   /* numpy */
+    const uint32_t* path_seeds;              /* numpy, optional; DEVICE ptr for mcr_run_batch_rng, HOST ptr for *_host_rng */
+} mcr_rng;
 
 /* One `OtherIncomeStreamConfig` (backend/config.py:12-47), raw field values. */
 typedef struct mcr_stream {
@@ -162,6 +187,17 @@ int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id,
 int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id,
                        uint64_t path_begin, uint64_t n_paths, int32_t working_months,
                        const double* injected_shocks, const mcr_outputs* out, int device);
+
+/* The same three entry points with an explicit random-stream descriptor (mcr_rng); the functions
+ * above are the MCR_RNG_PHILOX special case. */
+int mcr_run_batch_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                      uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                      const mcr_outputs* out, int device, void* hip_stream);
+int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                           uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                           const mcr_outputs* out, int device);
+int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
+                             int32_t n_months, double rho, double* out, int device);
 
 /* _draw_shock_path (simulation.py:452-466) for n_paths paths: host out [n_paths][n_months][3]. */
 int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,

@@ -12,13 +12,16 @@ import os
 import threading
 from typing import Optional
 
-MCR_ABI_VERSION = 1
+MCR_ABI_VERSION = 2
 MCR_MAX_STREAMS = 16
 MCR_N_COUNTERS = 2
 MCR_CTR_SUCCESS = 0
 MCR_CTR_PATHS = 1
 MCR_STREAM_SEARCH = 0
 MCR_STREAM_FINAL = 1
+MCR_RNG_PHILOX = 0
+MCR_RNG_NUMPY = 1
+MCR_MAX_ENTROPY_WORDS = 8
 
 MCR_HELPER_WITHDRAW = 0
 MCR_HELPER_NLV = 1
@@ -71,6 +74,48 @@ class McrParams(C.Structure):
     ]
 
 
+class McrRng(C.Structure):
+    """Random-stream descriptor (include/mcr.h: mcr_rng)."""
+
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("n_entropy_words", C.c_uint32),
+        ("entropy", C.c_uint32 * MCR_MAX_ENTROPY_WORDS),
+        ("philox_seed", C.c_uint64),
+        ("child_offset", C.c_uint64),
+        ("path_seeds", C.c_void_p),
+    ]
+
+
+def philox_rng(seed: int) -> McrRng:
+    r = McrRng()
+    r.kind = MCR_RNG_PHILOX
+    r.philox_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return r
+
+
+def numpy_rng(main_seed: int, child_offset: int = 0, path_seeds_ptr: int = 0) -> McrRng:
+    """The reference's NumPy stream for `main_seed` (SeedSequence entropy words, least significant first)."""
+    words, s = [], int(main_seed)
+    if s < 0:
+        raise ValueError("seed must be nonnegative")
+    while True:
+        words.append(s & 0xFFFFFFFF)
+        s >>= 32
+        if s == 0:
+            break
+    if len(words) > MCR_MAX_ENTROPY_WORDS:
+        raise ValueError(f"numpy rng: seeds above {32 * MCR_MAX_ENTROPY_WORDS} bits are not supported")
+    r = McrRng()
+    r.kind = MCR_RNG_NUMPY
+    r.n_entropy_words = len(words)
+    for i, w in enumerate(words):
+        r.entropy[i] = w
+    r.child_offset = int(child_offset)
+    r.path_seeds = path_seeds_ptr or None
+    return r
+
+
 class McrSizes(C.Structure):
     _fields_ = [
         ("total_months", C.c_int32),
@@ -113,6 +158,9 @@ ABI_SYMBOLS = (
     "mcr_run_batch",
     "mcr_run_batch_host",
     "mcr_draw_shocks_host",
+    "mcr_run_batch_rng",
+    "mcr_run_batch_host_rng",
+    "mcr_draw_shocks_host_rng",
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
@@ -155,6 +203,20 @@ def _declare(lib: C.CDLL) -> None:
     lib.mcr_draw_shocks_host.argtypes = [
         C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_double,
         C.c_void_p, C.c_int,
+    ]
+    lib.mcr_run_batch_rng.restype = C.c_int
+    lib.mcr_run_batch_rng.argtypes = [
+        P(McrParams), P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
+        C.c_void_p, P(McrOutputs), C.c_int, C.c_void_p,
+    ]
+    lib.mcr_run_batch_host_rng.restype = C.c_int
+    lib.mcr_run_batch_host_rng.argtypes = [
+        P(McrParams), P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
+        C.c_void_p, P(McrOutputs), C.c_int,
+    ]
+    lib.mcr_draw_shocks_host_rng.restype = C.c_int
+    lib.mcr_draw_shocks_host_rng.argtypes = [
+        P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_double, C.c_void_p, C.c_int,
     ]
     lib.mcr_eval_helper_host.restype = C.c_int
     lib.mcr_eval_helper_host.argtypes = [

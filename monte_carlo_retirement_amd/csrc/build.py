@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["mcr_hip.hip", "mcr_aggregate.hip"]
-HEADERS = ["mcr_device.h", "mcr_math.h", "mcr_tables.h", "mcr_host.h", os.path.join("..", "..", "include", "mcr.h")]
+HEADERS = ["mcr_device.h", "mcr_math.h", "mcr_tables.h", "mcr_numpy_rng.h", "mcr_numpy_tables.h", "mcr_host.h", os.path.join("..", "..", "include", "mcr.h")]
 TARGET = os.path.join(HERE, "libmcr_hip.so")
 ARCH = "gfx950"
 # -ffp-contract=off: every a*b+c rounds twice, like the reference's Python floats.

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mcr_device.h"
+#include "mcr_numpy_rng.h"
 #include "mcr_host.h"
 
 namespace mcr {
@@ -28,24 +29,31 @@ namespace mcr {
 // K1: the per-path state machine (_run_single_simulation_path, simulation.py:476-950)
 // ---------------------------------------------------------------------------------------------
 struct KernelIO {
-    uint64_t seed;
+    uint64_t seed;           // Philox key
     uint64_t path_begin;
     uint64_t n_paths;
     const double* injected;  // [n_paths][shock_rows][3] or nullptr
     mcr_outputs out;
     uint32_t stream_id;
+    // MCR_RNG_NUMPY (mcr_numpy_rng.h)
+    uint32_t n_entropy;
+    uint32_t entropy[MCR_MAX_ENTROPY_WORDS];
+    uint64_t child_offset;
+    const uint32_t* path_seeds;  // [n_paths] explicit seeds or nullptr
 };
 
 __device__ __forceinline__ double nan_f64() { return __longlong_as_double(0x7ff8000000000000LL); }
 
-template <int MODE>
+template <int MODE, int RNG>
 __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const KernelIO io) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // LDS: math tables (mcr_math.h), [n_lock_slots][kBlock] doubles (frozen nominal stream amounts),
-    // then block counters
+    // LDS: math tables (mcr_math.h), [numpy ziggurat tables], [n_lock_slots][kBlock] doubles (frozen
+    // nominal stream amounts), then block counters
     double* tab = reinterpret_cast<double*>(smem_raw);
     load_math_tables(tab, threadIdx.x, kBlock);
-    double* lock_lds = tab + kTabDoubles;
+    ZigTables zig{nullptr, nullptr, nullptr};
+    if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw + kMathTabBytes, threadIdx.x, kBlock);
+    double* lock_lds = reinterpret_cast<double*>(smem_raw + kMathTabBytes + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0));
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
     // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram
     const int ry = P.retirement_years;
@@ -72,10 +80,23 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
             if (rtraj) rtraj[(int64_t)t * stride + (int64_t)li] = px > kEps ? nominal / px : 0.0;
         }
     };
+    Pcg64 gen;  // NumPy stream: one generator per path, rows are consumed strictly in order
+    if (RNG == (int)MCR_RNG_NUMPY && !inj) {
+        const uint32_t s32 = io.path_seeds ? io.path_seeds[li]
+                                           : np_path_seed(io.entropy, (int)io.n_entropy, io.stream_id, io.child_offset + path);
+        pcg64_seed_u32(gen, s32);
+    }
     auto shocks = [&](int row, double& ze, double& zi, double& zp) {
         if (inj) {
             const int r = row < P.shock_rows - 1 ? row : P.shock_rows - 1;  // :692
             ze = inj[3 * r + 0]; zi = inj[3 * r + 1]; zp = inj[3 * r + 2];
+        } else if (RNG == (int)MCR_RNG_NUMPY) {
+            const double z0 = np_standard_normal(gen, zig);  // standard_normal((n, 3)) fills row-major (:458)
+            const double z1 = np_standard_normal(gen, zig);
+            const double z2 = np_standard_normal(gen, zig);
+            ze = z0;
+            zi = P.rho * z0 + P.rho_c * z1;                  // :461-464
+            zp = z2;
         } else {
             shock_row(io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, tab, ze, zi, zp);
         }
@@ -326,6 +347,24 @@ __global__ void shocks_kernel(uint64_t seed, uint32_t stream_id, uint64_t path_b
     out[3 * idx + 0] = ze; out[3 * idx + 1] = zi; out[3 * idx + 2] = zp;
 }
 
+// _draw_shock_path with the reference's NumPy stream: one thread per path, rows in order
+__global__ void np_shocks_kernel(const KernelIO io, int32_t n_months, double rho, double rho_c, double* out) {
+    __shared__ __align__(16) unsigned char zraw[kZigLdsBytes];
+    const ZigTables zig = load_zig_tables(zraw, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= io.n_paths) return;
+    Pcg64 g;
+    const uint32_t s32 = io.path_seeds ? io.path_seeds[i]
+                                       : np_path_seed(io.entropy, (int)io.n_entropy, io.stream_id, io.child_offset + io.path_begin + i);
+    pcg64_seed_u32(g, s32);
+    double* o = out + (size_t)i * 3u * (size_t)n_months;
+    for (int32_t m = 0; m < n_months; ++m) {
+        const double z0 = np_standard_normal(g, zig), z1 = np_standard_normal(g, zig), z2 = np_standard_normal(g, zig);
+        o[3 * m + 0] = z0; o[3 * m + 1] = rho * z0 + rho_c * z1; o[3 * m + 2] = z2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -444,16 +483,37 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     return MCR_OK;
 }
 
-static size_t path_kernel_lds_bytes(const DevParams& d) {
-    return (size_t)kMathTabBytes + (size_t)d.n_lock_slots * kBlock * sizeof(double) +
+static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng) {
+    return (size_t)kMathTabBytes + (numpy_rng ? (size_t)kZigLdsBytes : 0) + (size_t)d.n_lock_slots * kBlock * sizeof(double) +
            (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1)) * sizeof(unsigned int);
 }
 
-static int launch_paths(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,
+static int check_rng(const mcr_rng* rng) {
+    if (!rng) { set_error("null rng"); return MCR_ERR_INVALID_ARG; }
+    if (rng->kind != MCR_RNG_PHILOX && rng->kind != MCR_RNG_NUMPY) { set_error("unknown rng kind %u", rng->kind); return MCR_ERR_INVALID_ARG; }
+    if (rng->kind == MCR_RNG_NUMPY && !rng->path_seeds &&
+        (rng->n_entropy_words < 1 || rng->n_entropy_words > MCR_MAX_ENTROPY_WORDS)) {
+        set_error("numpy rng: main seed must have 1..%d uint32 words (got %u)", MCR_MAX_ENTROPY_WORDS, rng->n_entropy_words);
+        return MCR_ERR_INVALID_ARG;
+    }
+    return MCR_OK;
+}
+
+static void fill_io_rng(KernelIO& io, const mcr_rng* rng, const uint32_t* device_path_seeds) {
+    io.seed = rng->philox_seed;
+    io.n_entropy = rng->n_entropy_words;
+    for (int i = 0; i < MCR_MAX_ENTROPY_WORDS; ++i) io.entropy[i] = rng->entropy[i];
+    io.child_offset = rng->child_offset;
+    io.path_seeds = device_path_seeds;
+}
+
+static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
                         uint64_t n_paths, int32_t wm, const double* injected, const mcr_outputs* out,
                         hipStream_t stream) {
     DevParams d;
     int rc = derive_params(p, wm, &d);
+    if (rc != MCR_OK) return rc;
+    rc = check_rng(rng);
     if (rc != MCR_OK) return rc;
     if (!out) { set_error("null outputs"); return MCR_ERR_INVALID_ARG; }
     if (n_paths == 0) return MCR_OK;
@@ -465,22 +525,28 @@ static int launch_paths(const mcr_params* p, uint64_t seed, uint32_t stream_id, 
                               out->inflation_at_retirement || out->success;
     KernelIO io;
     std::memset(&io, 0, sizeof(io));
-    io.seed = seed; io.stream_id = stream_id; io.path_begin = path_begin; io.n_paths = n_paths;
+    fill_io_rng(io, rng, rng->path_seeds);
+    io.stream_id = stream_id; io.path_begin = path_begin; io.n_paths = n_paths;
     io.injected = injected; io.out = *out;
     if (io.out.path_stride <= 0) io.out.path_stride = (int64_t)n_paths;
     if (want_traj && (uint64_t)io.out.path_stride < n_paths) {
         set_error("path_stride %lld < n_paths %llu", (long long)io.out.path_stride, (unsigned long long)n_paths);
         return MCR_ERR_INVALID_ARG;
     }
-    const size_t lds = path_kernel_lds_bytes(d);
+    const bool np_rng = rng->kind == MCR_RNG_NUMPY;
+    const size_t lds = path_kernel_lds_bytes(d, np_rng);
     if (lds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
-    if (want_traj)
-        hipLaunchKernelGGL(path_kernel<2>, grid, block, lds, stream, d, io);
-    else if (want_summary)
-        hipLaunchKernelGGL(path_kernel<1>, grid, block, lds, stream, d, io);
-    else
-        hipLaunchKernelGGL(path_kernel<0>, grid, block, lds, stream, d, io);
+    const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
+    if (!np_rng) {
+        if (mode == 2) hipLaunchKernelGGL((path_kernel<2, 0>), grid, block, lds, stream, d, io);
+        else if (mode == 1) hipLaunchKernelGGL((path_kernel<1, 0>), grid, block, lds, stream, d, io);
+        else hipLaunchKernelGGL((path_kernel<0, 0>), grid, block, lds, stream, d, io);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((path_kernel<2, 1>), grid, block, lds, stream, d, io);
+        else if (mode == 1) hipLaunchKernelGGL((path_kernel<1, 1>), grid, block, lds, stream, d, io);
+        else hipLaunchKernelGGL((path_kernel<0, 1>), grid, block, lds, stream, d, io);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "path_kernel launch");
     return MCR_OK;
@@ -513,19 +579,43 @@ int32_t mcr_stream_start_month_index(double current_age, int32_t working_months,
     return start_month_index(current_age, working_months, start_at_age);
 }
 
+static mcr_rng philox_rng(uint64_t seed) {
+    mcr_rng r;
+    std::memset(&r, 0, sizeof(r));
+    r.kind = MCR_RNG_PHILOX;
+    r.philox_seed = seed;
+    return r;
+}
+
+int mcr_run_batch_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                      uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                      const mcr_outputs* out, int device, void* hip_stream) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    return launch_paths(p, rng, stream_id, path_begin, n_paths, working_months, injected_shocks, out,
+                        (hipStream_t)hip_stream);
+}
+
 int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,
                   uint64_t n_paths, int32_t working_months, const double* injected_shocks,
                   const mcr_outputs* out, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
-    return launch_paths(p, seed, stream_id, path_begin, n_paths, working_months, injected_shocks, out,
-                        (hipStream_t)hip_stream);
+    const mcr_rng r = philox_rng(seed);
+    return mcr_run_batch_rng(p, &r, stream_id, path_begin, n_paths, working_months, injected_shocks, out, device, hip_stream);
 }
 
 int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,
                        uint64_t n_paths, int32_t working_months, const double* injected_shocks,
                        const mcr_outputs* out, int device) {
+    const mcr_rng r = philox_rng(seed);
+    return mcr_run_batch_host_rng(p, &r, stream_id, path_begin, n_paths, working_months, injected_shocks, out, device);
+}
+
+int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng_in, uint32_t stream_id, uint64_t path_begin,
+                           uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                           const mcr_outputs* out, int device) {
     int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    rc = check_rng(rng_in);
     if (rc != MCR_OK) return rc;
     mcr_sizes sz;
     rc = query_sizes(p, working_months, &sz);
@@ -581,8 +671,15 @@ int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id, u
         e = arena.alloc((void**)&d_inj, bytes);
         if (e == hipSuccess) e = hipMemcpy(d_inj, injected_shocks, bytes, hipMemcpyHostToDevice);
     }
+    mcr_rng rng = *rng_in;
+    if (rng.path_seeds && e == hipSuccess) {  // explicit per-path seeds: upload
+        uint32_t* d_seeds = nullptr;
+        e = arena.alloc((void**)&d_seeds, n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(d_seeds, rng.path_seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        rng.path_seeds = d_seeds;
+    }
     if (e != hipSuccess) return hip_fail(e, "device allocation / upload");
-    rc = launch_paths(p, seed, stream_id, path_begin, n_paths, working_months, d_inj, &d, nullptr);
+    rc = launch_paths(p, &rng, stream_id, path_begin, n_paths, working_months, d_inj, &d, nullptr);
     if (rc != MCR_OK) return rc;
     e = hipDeviceSynchronize();
     if (e != hipSuccess) return hip_fail(e, "path_kernel execution");
@@ -596,8 +693,17 @@ int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id, u
 
 int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                          int32_t n_months, double rho, double* out, int device) {
+    const mcr_rng r = philox_rng(seed);
+    return mcr_draw_shocks_host_rng(&r, stream_id, path_begin, n_paths, n_months, rho, out, device);
+}
+
+int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
+                             int32_t n_months, double rho, double* out, int device) {
     int rc = use_device(device);
     if (rc != MCR_OK) return rc;
+    rc = check_rng(rng);
+    if (rc != MCR_OK) return rc;
+    const uint64_t seed = rng->philox_seed;
     if (!out || n_months < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     const uint64_t total = n_paths * (uint64_t)n_months;
     if (total == 0) return MCR_OK;
@@ -608,8 +714,22 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
     if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     const double om = 1.0 - rho * rho;
     const double rho_c = std::sqrt(om > 0.0 ? om : 0.0);
-    hipLaunchKernelGGL(shocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, seed,
-                       stream_id, path_begin, n_paths, n_months, rho, rho_c, d);
+    if (rng->kind == MCR_RNG_NUMPY) {
+        KernelIO io;
+        std::memset(&io, 0, sizeof(io));
+        uint32_t* d_seeds = nullptr;
+        if (rng->path_seeds) {
+            e = arena.alloc((void**)&d_seeds, (size_t)n_paths * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(d_seeds, rng->path_seeds, (size_t)n_paths * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return hip_fail(e, "seed upload");
+        }
+        fill_io_rng(io, rng, d_seeds);
+        io.stream_id = stream_id; io.path_begin = path_begin; io.n_paths = n_paths;
+        hipLaunchKernelGGL(np_shocks_kernel, dim3((unsigned)((n_paths + 63) / 64)), dim3(64), 0, nullptr, io, n_months, rho, rho_c, d);
+    } else {
+        hipLaunchKernelGGL(shocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, seed,
+                           stream_id, path_begin, n_paths, n_months, rho, rho_c, d);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hip_fail(e, "shocks_kernel");

@@ -17,7 +17,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _native as N
-from ._native import McrOutputs, McrParams, McrSizes
+from ._native import McrOutputs, McrParams, McrRng, McrSizes
 
 SUMMARY_FIELDS = (
     "start_balance",
@@ -42,9 +42,14 @@ def stream_start_month_index(current_age: float, working_months: int, start_at_a
     return int(N.load_library().mcr_stream_start_month_index(current_age, working_months, start_at_age))
 
 
+def _as_rng(seed) -> McrRng:
+    """`seed` may be an int (Philox key) or a ready McrRng descriptor."""
+    return seed if isinstance(seed, McrRng) else N.philox_rng(int(seed))
+
+
 def run_batch_host(
     params: McrParams,
-    seed: int,
+    seed,
     stream_id: int,
     path_begin: int,
     n_paths: int,
@@ -54,8 +59,12 @@ def run_batch_host(
     want_trajectories: bool = True,
     want_bins: bool = True,
     device: int = 0,
+    path_seeds: Optional[np.ndarray] = None,
 ) -> Dict[str, np.ndarray]:
     """Simulate paths [path_begin, path_begin+n_paths) on the GPU; numpy arrays out.
+
+    ``seed``: int (Philox key) or an ``McrRng`` (e.g. ``_native.numpy_rng(main_seed, child_offset)``);
+    ``path_seeds``: explicit uint32 seed per path for the NumPy stream.
 
     Keys follow ``mcr_outputs``: the six float summary fields + ``success`` (uint8),
     ``trajectory``/``real_trajectory`` ``[T, n]``, ``withdrawal_rate_trajectory`` ``[ry, n]``,
@@ -95,25 +104,38 @@ def run_batch_host(
         if inj_arr.shape != (n, sz.shock_rows, 3):
             raise ValueError(f"injected_shocks shape {inj_arr.shape} != {(n, sz.shock_rows, 3)}")
         inj = inj_arr.ctypes.data
-    rc = lib.mcr_run_batch_host(
-        C.byref(params), int(seed), int(stream_id), int(path_begin), n, int(working_months),
+    rng = _as_rng(seed)
+    seeds_arr = None
+    if path_seeds is not None:
+        seeds_arr = np.ascontiguousarray(path_seeds, dtype=np.uint32)
+        if seeds_arr.shape != (n,):
+            raise ValueError("path_seeds must have one uint32 per path")
+        rng.path_seeds = seeds_arr.ctypes.data
+    rc = lib.mcr_run_batch_host_rng(
+        C.byref(params), C.byref(rng), int(stream_id), int(path_begin), n, int(working_months),
         inj, C.byref(o), int(device),
     )
-    N.check(rc, "mcr_run_batch_host")
+    N.check(rc, "mcr_run_batch_host_rng")
     return res
 
 
 def draw_shocks_host(
-    seed: int, stream_id: int, path_begin: int, n_paths: int, n_months: int, rho: float, device: int = 0
+    seed, stream_id: int, path_begin: int, n_paths: int, n_months: int, rho: float, device: int = 0,
+    path_seeds: Optional[np.ndarray] = None,
 ) -> np.ndarray:
     """Engine shock rows ``[n_paths, n_months, 3]`` (equity, inflation, premium) from the GPU."""
     N.require_device()
     out = np.empty((int(n_paths), int(n_months), 3), dtype=np.float64)
-    rc = N.load_library().mcr_draw_shocks_host(
-        int(seed), int(stream_id), int(path_begin), int(n_paths), int(n_months), float(rho),
+    rng = _as_rng(seed)
+    seeds_arr = None
+    if path_seeds is not None:
+        seeds_arr = np.ascontiguousarray(path_seeds, dtype=np.uint32)
+        rng.path_seeds = seeds_arr.ctypes.data
+    rc = N.load_library().mcr_draw_shocks_host_rng(
+        C.byref(rng), int(stream_id), int(path_begin), int(n_paths), int(n_months), float(rho),
         out.ctypes.data, int(device),
     )
-    N.check(rc, "mcr_draw_shocks_host")
+    N.check(rc, "mcr_draw_shocks_host_rng")
     return out
 
 
@@ -195,14 +217,16 @@ class DeviceBatch:
         self.wr_obs_counts.zero_()
         self.ruin_year_bins.zero_()
 
-    def launch(self, seed: int, stream_id: int, path_begin: int, n_paths: Optional[int] = None) -> None:
-        """Enqueue one kernel launch over ``n_paths`` (default: the whole batch) on the current stream."""
+    def launch(self, seed, stream_id: int, path_begin: int, n_paths: Optional[int] = None) -> None:
+        """Enqueue one kernel launch over ``n_paths`` (default: the whole batch) on the current stream.
+        ``seed``: int (Philox key) or an ``McrRng`` descriptor."""
         n = self.n_paths if n_paths is None else int(n_paths)
         if n > self.n_paths:
             raise ValueError("launch larger than the batch buffers")
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._lib.mcr_run_batch(
-            C.byref(self.params), int(seed), int(stream_id), int(path_begin), n,
+        rng = _as_rng(seed)
+        rc = self._lib.mcr_run_batch_rng(
+            C.byref(self.params), C.byref(rng), int(stream_id), int(path_begin), n,
             self.working_months, None, C.byref(self._out), self.device, C.c_void_p(stream),
         )
-        N.check(rc, "mcr_run_batch")
+        N.check(rc, "mcr_run_batch_rng")

@@ -135,7 +135,15 @@ def _fold_seed_u64(seed: int) -> int:
 class RetirementMonteCarloSimulator:
     """Monte Carlo retirement simulator whose paths run on an MI355X (see module docstring)."""
 
-    def __init__(self, params_model: Config, main_seed_override: Optional[int] = None, device: int = 0):
+    def __init__(self, params_model: Config, main_seed_override: Optional[int] = None, device: int = 0,
+                 rng: str = "philox"):
+        """``rng="philox"`` (default): the engine's counter-based stream; ``path_seed`` = global path
+        index.  ``rng="numpy"``: the reference's OWN stream reproduced on the device (SeedSequence ->
+        PCG64 -> ziggurat): the same ``seed`` then yields the reference's numbers, ``path_seed`` is the
+        reference's uint32 path seed and `_path_seeds` follows its spawn-and-cache rule (:187-199)."""
+        if rng not in ("philox", "numpy"):
+            raise ValueError("rng must be 'philox' or 'numpy'")
+        self.rng = rng
         self.params_model = params_model.model_copy(deep=True)  # simulation.py:136
 
         if main_seed_override is not None:  # :138-145
@@ -152,6 +160,10 @@ class RetirementMonteCarloSimulator:
         self._stream_name = "final"
         self._engine_seed = _fold_seed_u64(self.main_seed)
         self.device = int(device)
+        # NumPy stream bookkeeping: children spawned so far per stream, and the offset at which each
+        # (stream, n) batch was spawned — the reference's _path_seed_cache rule (:154, :192-199)
+        self._np_children_spawned = {"search": 0, "final": 0}
+        self._np_batch_offset: Dict[Tuple[str, int], int] = {}
 
         p = self.params_model
         self._inv1_mu_log, self._inv1_sigma_log = arithmetic_to_log_params(  # :157-166
@@ -181,9 +193,31 @@ class RetirementMonteCarloSimulator:
         self._stream_name = "final"
 
     def _path_seeds(self, num_simulations: int) -> List[int]:
-        """Path identifiers of a batch.  In this engine a path's "seed" is its global index in the
-        active stream: the same list for every working-month candidate (common random numbers)."""
-        return list(range(int(num_simulations)))
+        """Path identifiers of a batch.  Philox stream: a path's "seed" is its global index in the
+        active stream.  NumPy stream: the reference's uint32 seeds, spawned once per (stream, n) and
+        cached (:187-199).  Either way the list is the same for every working-month candidate."""
+        n = int(num_simulations)
+        if self.rng == "philox":
+            return list(range(n))
+        off = self._np_offset(n)  # children (stream, off .. off+n-1) of SeedSequence(main_seed)
+        return [
+            int(np.random.SeedSequence(self.main_seed, spawn_key=(self._stream_id, off + j)).generate_state(1)[0])
+            for j in range(n)
+        ]
+
+    def _np_offset(self, n: int) -> int:
+        """Spawn offset of the (active stream, n) batch: assigned on first use, then cached."""
+        key = (self._stream_name, int(n))
+        if key not in self._np_batch_offset:
+            self._np_batch_offset[key] = self._np_children_spawned[self._stream_name]
+            self._np_children_spawned[self._stream_name] += int(n)
+        return self._np_batch_offset[key]
+
+    def _batch_rng(self, n: int):
+        """RNG descriptor of an n-path batch on the active stream (int = Philox key)."""
+        if self.rng == "philox":
+            return self._engine_seed
+        return N.numpy_rng(self.main_seed, child_offset=self._np_offset(n))
 
     # ---- scalar helpers: evaluated by the SAME device functions the path kernel inlines -----------
     def _calculate_withdrawal_and_update(
@@ -235,6 +269,11 @@ class RetirementMonteCarloSimulator:
     def _draw_shock_path(self, n_months: int, path_seed: int) -> np.ndarray:
         """Shock rows (equity, inflation, premium) of one path, shape (n_months, 3) — the engine's
         replacement of simulation.py:452-466."""
+        if self.rng == "numpy":
+            return E.draw_shocks_host(
+                N.numpy_rng(self.main_seed), self._stream_id, 0, 1, int(n_months), self._equity_inflation_rho,
+                self.device, path_seeds=np.array([int(path_seed)], dtype=np.uint32),
+            )[0]
         return E.draw_shocks_host(
             self._engine_seed, self._stream_id, int(path_seed), 1, int(n_months), self._equity_inflation_rho,
             self.device,
@@ -251,10 +290,17 @@ class RetirementMonteCarloSimulator:
         self, working_months: int, path_seed: int
     ) -> Dict[str, Union[float, List[float]]]:
         """Simulate ONE path on the device and return the reference's 10-key dict."""
-        r = E.run_batch_host(
-            self._current_params(), self._engine_seed, self._stream_id, int(path_seed), 1,
-            int(working_months), want_bins=False, device=self.device,
-        )
+        if self.rng == "numpy":
+            r = E.run_batch_host(
+                self._current_params(), N.numpy_rng(self.main_seed), self._stream_id, 0, 1,
+                int(working_months), want_bins=False, device=self.device,
+                path_seeds=np.array([int(path_seed)], dtype=np.uint32),
+            )
+        else:
+            r = E.run_batch_host(
+                self._current_params(), self._engine_seed, self._stream_id, int(path_seed), 1,
+                int(working_months), want_bins=False, device=self.device,
+            )
         return {
             "Start Balance": float(r["start_balance"][0]),
             "Final Balance": float(r["final_balance"][0]),
@@ -290,7 +336,7 @@ class RetirementMonteCarloSimulator:
         wm = int(working_months)
         logger.debug(f"Running {n} simulations on HIP device {self.device} for {wm} working months.")
         batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=self.device)
-        batch.launch(self._engine_seed, self._stream_id, 0)
+        batch.launch(self._batch_rng(n), self._stream_id, 0)
 
         cols = {name: batch.summary[field].cpu().numpy() for name, field in _FIELD_OF.items()}
         cols["Success"] = batch.success.cpu().numpy().astype(bool)
@@ -347,11 +393,11 @@ class RetirementMonteCarloSimulator:
             params = self._current_params()
             red = D.run_sharded_counts(
                 n, params.retirement_years,
-                D.gpu_count_runner(params, self._engine_seed, self._stream_id, int(working_months)),
+                D.gpu_count_runner(params, self._batch_rng(n), self._stream_id, int(working_months)),
             )
             return red.success_probability_pct
         batch = E.DeviceBatch(self._current_params(), int(working_months), n, want="count", device=self.device)
-        batch.launch(self._engine_seed, self._stream_id, 0)
+        batch.launch(self._batch_rng(n), self._stream_id, 0)
         ok = int(batch.counters[N.MCR_CTR_SUCCESS].item())
         return float(np.float64(ok) / np.float64(n) * 100.0)
 

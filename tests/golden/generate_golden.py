@@ -423,6 +423,40 @@ def gen_numpy_native(outdir):
     return meta
 
 
+def gen_numpy_native_batch():
+    """Reference driven by its OWN NumPy RNG, no injection: the literal-seed fixtures for the
+    engine's rng="numpy" mode.  Per-path results with the uint32 path seeds, and a native search."""
+    out = {"paths": [], "search": []}
+    tab = {t[0]: t for t in scenario_table()}
+    for name, seed, n in [("C1_config_json_wm233", 12345, 24), ("C3_jorge_wm75_rho03", 2024, 24),
+                          ("FAILING_wm24", 99, 32), ("ANNUAL_wm50", 777, 24), ("PRETAX_wm14", 4242, 16)]:
+        _, cfgd, wm, _stream, _seed, _n = tab[name]
+        for stream in ("final", "search"):
+            sim = make_sim(dict(cfgd, num_processes=1), seed=seed)
+            getattr(sim, f"use_{stream}_seeds")()
+            first = sim._path_seeds(7)          # an earlier batch of another size shifts the spawn offset (:192-199)
+            seeds = sim._path_seeds(n)
+            res = [result_to_jsonable(sim._run_single_simulation_path(wm, s)) for s in seeds]
+            out["paths"].append({"name": name, "cfg": cfgd, "working_months": wm, "main_seed": seed, "stream": stream,
+                                 "earlier_batch": 7, "earlier_seeds": [int(x) for x in first],
+                                 "numpy_path_seeds": [int(x) for x in seeds], "results": res})
+        print(f"  native batch {name}: ok", flush=True)
+    for name, cfgd, seed in [("C3_jorge_search_native", dict(load_json("jorge.json"), num_processes=1), 12345)]:
+        sim = make_sim(cfgd, seed=seed)
+        events = []
+        months, prob, curve = sim.find_minimum_working_months(verbose=False, progress_callback=events.append)
+        sim.use_final_seeds()
+        t = sim.run_monte_carlo_simulations(months, cfgd["num_simulations_main"])
+        out["search"].append({"name": name, "cfg": cfgd, "seed": seed, "months": months, "probability": prob,
+                              "search_curve": curve, "events": events,
+                              "final_success_probability": sim._success_probability(t[0]),
+                              "final_success": [bool(x) for x in t[0]["Success"].tolist()],
+                              "final_trajectory_percentiles": frame_to_jsonable(t[1]),
+                              "final_wr_observation_counts": t[6]})
+        print(f"  native search {name}: {months} months @ {prob:.2f}%, final {out['search'][-1]['final_success_probability']:.2f}%", flush=True)
+    return out
+
+
 def frame_to_jsonable(df):
     if df is None:
         return None
@@ -561,6 +595,8 @@ def main():
         dump("aggregation.json", gen_aggregation())
     if want("search"):
         dump("search.json", gen_search())
+    if want("native_batch"):
+        dump("numpy_native_batch.json", gen_numpy_native_batch())
     if want("native_stats"):
         dump("numpy_native_stats.json", gen_native_stats())
     if want("10k") and not args.skip_10k:
