@@ -58,6 +58,52 @@ def cpu_baseline(params, n_threads: int, paths_per_thread: int):
     return sum(done) / dt, dt
 
 
+def aux_hbm_kernels(torch, n):
+    """The HBM-side kernels of the path on the BASELINE configs[2] shape (jorge.json + rho=0.3, wm=75:
+    T=48 yearly samples, 40 WR rows), n paths: K1 with full trajectory output (write efficiency), K3
+    row quantiles and K2 histogram (achieved algorithmic GB/s vs the 8 TB/s HBM peak).  Not part of
+    `value`; reported so the memory-bound side of the path has a measured roofline too."""
+    from monte_carlo_retirement_amd import Config, params_from_config
+    from monte_carlo_retirement_amd import aggregation as A
+    from monte_carlo_retirement_amd import engine as E
+
+    with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
+        cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3, seed=12345))
+    p = params_from_config(cfg)
+    b = E.DeviceBatch(p, 75, n, want="full")
+    T, ry = b.sizes.trajectory_len, b.sizes.retirement_years
+
+    def timed(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    b.launch(12345, 1, 0)
+    ms_k1 = timed(lambda: b.launch(12345, 1, 0))
+    bytes_k1 = n * (8 * (2 * T + ry + 6) + 1)
+    ms_k3 = timed(lambda: (A.row_quantiles(b.trajectory, n, A.TRAJECTORY_QUANTILES),
+                           A.row_quantiles(b.real_trajectory, n, A.TRAJECTORY_QUANTILES),
+                           A.row_quantiles(b.withdrawal_rate_trajectory, n, A.WR_QUANTILES)))
+    bytes_k3 = 4 * 8 * n * (2 * T + ry)  # four streaming digit passes over the slab; passes 4-7 read only candidates
+    ms_k2 = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 100))
+    bytes_k2 = 2 * 9 * n                 # min/max pass + bin pass, 8 B value + 1 B flag each
+    return {
+        "workload": f"BASELINE configs[2] shape: jorge.json rho=0.3, wm=75 (555 months), {n} paths, T={T}, ry={ry}",
+        "K1_full_output": {"ms": ms_k1, "paths_per_s": n / ms_k1 * 1e3, "algorithmic_write_bytes": bytes_k1,
+                           "write_GBps": bytes_k1 / ms_k1 / 1e6, "frac_of_hbm_peak": bytes_k1 / ms_k1 / 1e6 / HBM_PEAK_GBS,
+                           "note": "compute-bound: the time-major trajectory stores hide under the fp64 VALU work"},
+        "K3_row_quantiles": {"ms": ms_k3, "rows": 2 * T + ry, "algorithmic_read_bytes": bytes_k3,
+                             "GBps": bytes_k3 / ms_k3 / 1e6, "frac_of_hbm_peak": bytes_k3 / ms_k3 / 1e6 / HBM_PEAK_GBS,
+                             "note": "includes host-side scratch allocation and result download of three calls"},
+        "K2_histogram": {"ms": ms_k2, "algorithmic_bytes": bytes_k2, "GBps": bytes_k2 / ms_k2 / 1e6},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,8 +111,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--paths", type=int, default=1_000_000, help="paths per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the HBM-side kernels (trajectory write / quantiles / histogram)")
+    ap.add_argument("--aux-paths", type=int, default=4_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--cpu-paths-per-thread", type=int, default=40_000)
+    ap.add_argument("--cpu-paths-per-thread", type=int, default=160_000)
     args = ap.parse_args()
 
     import torch
@@ -170,6 +218,8 @@ def main():
             },
             "success_probability": counters[0] / max(1, counters[1]),
         }
+        if not args.no_aux and world == 1:
+            out["hbm_kernels"] = aux_hbm_kernels(torch, args.aux_paths)
         if not args.no_cpu_baseline and world == 1:
             v, secs = cpu_baseline(params, args.cpu_threads, args.cpu_paths_per_thread)
             out["cpu_baseline"] = {
