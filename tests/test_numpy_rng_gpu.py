@@ -92,3 +92,29 @@ def test_native_success_rate_equals_reference_at_4000_paths():
         assert int(res["counters"][0]) == round(g["success_probability_pct"] * n / 100.0), g["name"]
         assert float(np.median(res["final_balance"])) == pytest.approx(g["median_final_balance"], rel=REL)
         assert float(np.median(res["start_balance"])) == pytest.approx(g["median_start_balance"], rel=REL)
+
+
+def test_cli_flow_reproduces_the_references_surveyed_numbers():
+    """BASELINE.md §2 / SURVEY §6, measured on the REFERENCE with seed 12345: jorge.json ->
+    33 probes, 75 months @ 99.0 %, final N=1000 98.5 %; config.json (num_simulations_search=300) ->
+    29 probes, 233 months @ 98.0 %, final 97.9 %.  The CLI-shaped caller with rng=numpy must print
+    exactly those numbers."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    def run(cfg, *extra):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "examples", "run_scenario.py"),
+                              os.path.join(REPO, "scenarios", cfg), "--seed", "12345", "--rng", "numpy", *extra],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    j = run("jorge.json")
+    assert (j["required_working_months"], j["search_probes"], j["success_probability"]) == (75, 33, 98.5)
+    c = run("config.json")
+    assert (c["required_working_months"], c["search_probes"], c["success_probability"]) == (233, 29, 97.9)
+    assert c["trajectory_years"] == 71 and c["sample_paths"] == 5
