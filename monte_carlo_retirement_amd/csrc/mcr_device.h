@@ -72,25 +72,53 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// One shock row (equity, inflation, premium); replaces row `month` of _draw_shock_path (:452-466).
-//   u = (x + 0.5) * 2^-32 in (0,1);  (z0, z1) = sqrt(-2 ln u0) (cos, sin)(2 pi u1);
-//   z2 = sqrt(-2 ln u2) cos(2 pi u3);  equity = z0, inflation = rho z0 + rho_c z1, premium = z2.
-__device__ __forceinline__ void shock_row(uint64_t seed, uint32_t stream_id, uint64_t path,
-                                          uint32_t month, double rho, double rho_c, const double* tab,
-                                          double& z_eq, double& z_inf, double& z_prem) {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), month, stream_id, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), x);
-    // radius and angle are taken straight from the Philox integers (mcr_math.h)
-    const double r0 = fsqrt(neg2_log_u32(x[0], tab));
-    const double r1 = fsqrt(neg2_log_u32(x[2], tab));
-    double s, c, s_unused, c2;
-    sincos_u32<true>(x[1], tab, s, c);
-    sincos_u32<false>(x[3], tab, s_unused, c2);
-    const double z0 = r0 * c, z1 = r0 * s;
-    z_eq = z0;
-    z_inf = rho * z0 + rho_c * z1;
-    z_prem = r1 * c2;
+// The path's standard-normal sequence n[0], n[1], ... : pair j = Box-Muller of Philox words
+// (2(j&1), 2(j&1)+1) of block j>>1 (counter = (path_lo, path_hi, block, stream_id)):
+//   n[2j] = sqrt(-2 ln u_r) cos(2 pi u_a), n[2j+1] = ... sin(...),  u = (x + 0.5) 2^-32.
+// Shock row k = (n[3k], rho n[3k] + rho_c n[3k+1], n[3k+2])  (replaces _draw_shock_path, :452-466),
+// a pure function of (seed, stream, path, k): common random numbers across working-month candidates
+// and across any sharding.  Rows are consumed in order, so a lane carries the half-used pair / block:
+// 4 rows cost 3 Philox blocks and 6 (log, sqrt, sincos) pairs instead of 4 and 8.
+__device__ __forceinline__ void bm_pair(uint32_t xr, uint32_t xa, const double* tab, double& zc, double& zs) {
+    const double r = fsqrt(neg2_log_u32(xr, tab));  // radius and angle straight from the Philox integers
+    double s, c;
+    sincos_u32<true>(xa, tab, s, c);
+    zc = r * c;
+    zs = r * s;
+}
+
+struct ShockGen {      // per-lane carry between consecutive rows
+    double carry_z;    // second normal of a pair whose first was used by the previous row
+    uint32_t cw0, cw1; // words 2,3 of the last Philox block (the next pair)
+};
+
+// Row `k`, given that rows 0..k-1 of this path were generated by this ShockGen in order.
+__device__ __forceinline__ void shock_row_seq(ShockGen& G, uint64_t seed, uint32_t stream_id, uint64_t path,
+                                              uint32_t k, double rho, double rho_c, const double* tab,
+                                              double& z_eq, double& z_inf, double& z_prem) {
+    const uint32_t phase = k & 3u;  // wave-uniform
+    uint32_t x[4] = {0u, 0u, 0u, 0u};
+    if (phase != 3u)
+        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * (k >> 2) + phase, stream_id, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), x);
+    // pair A: phases 0,1 -> words 0,1 of the new block; phases 2,3 -> the carried words
+    const uint32_t ar = phase < 2u ? x[0] : G.cw0, aa = phase < 2u ? x[1] : G.cw1;
+    double ac, as;
+    bm_pair(ar, aa, tab, ac, as);
+    double n0, n1, n2;
+    if ((phase & 1u) == 0u) {  // rows 4t, 4t+2: (A.cos, A.sin, B.cos), B.sin carried
+        const uint32_t br = phase == 0u ? x[2] : x[0], ba = phase == 0u ? x[3] : x[1];
+        double bc, bs;
+        bm_pair(br, ba, tab, bc, bs);
+        n0 = ac; n1 = as; n2 = bc;
+        G.carry_z = bs;
+    } else {                   // rows 4t+1, 4t+3: (carried, A.cos, A.sin)
+        n0 = G.carry_z; n1 = ac; n2 = as;
+    }
+    if (phase == 1u || phase == 2u) { G.cw0 = x[2]; G.cw1 = x[3]; }
+    z_eq = n0;
+    z_inf = rho * n0 + rho_c * n1;
+    z_prem = n2;
 }
 
 // _monthly_gross_from_shock (:468-474) with a = mu_log/12 and b = sigma_log/sqrt(12) precomputed.

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
             if (rtraj) rtraj[(int64_t)t * stride + (int64_t)li] = px > kEps ? nominal / px : 0.0;
         }
     };
+    ShockGen sgen{0.0, 0u, 0u};  // Philox stream: carry between consecutive rows
     Pcg64 gen;  // NumPy stream: one generator per path, rows are consumed strictly in order
     if (RNG == (int)MCR_RNG_NUMPY && !inj) {
         const uint32_t s32 = io.path_seeds ? io.path_seeds[li]
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
             zi = P.rho * z0 + P.rho_c * z1;                  // :461-464
             zp = z2;
         } else {
-            shock_row(io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, tab, ze, zi, zp);
+            shock_row_seq(sgen, io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, tab, ze, zi, zp);
         }
     };
 
@@ -331,20 +332,18 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
     }
 }
 
-// _draw_shock_path (:452-466): out[n_paths][n_months][3]
+// _draw_shock_path (:452-466): out[n_paths][n_months][3]; one thread per path, rows in order
 __global__ void shocks_kernel(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                               int32_t n_months, double rho, double rho_c, double* out) {
     __shared__ double tab[kTabDoubles];
     load_math_tables(tab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = n_paths * (uint64_t)n_months;
-    if (idx >= total) return;
-    const uint64_t p = idx / (uint64_t)n_months;
-    const uint32_t m = (uint32_t)(idx % (uint64_t)n_months);
-    double ze, zi, zp;
-    shock_row(seed, stream_id, path_begin + p, m, rho, rho_c, tab, ze, zi, zp);
-    out[3 * idx + 0] = ze; out[3 * idx + 1] = zi; out[3 * idx + 2] = zp;
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    ShockGen G{0.0, 0u, 0u};
+    double* o = out + (size_t)p * 3u * (size_t)n_months;
+    for (int32_t m = 0; m < n_months; ++m)
+        shock_row_seq(G, seed, stream_id, path_begin + p, (uint32_t)m, rho, rho_c, tab, o[3 * m], o[3 * m + 1], o[3 * m + 2]);
 }
 
 // _draw_shock_path with the reference's NumPy stream: one thread per path, rows in order
@@ -727,7 +726,7 @@ int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t pa
         io.stream_id = stream_id; io.path_begin = path_begin; io.n_paths = n_paths;
         hipLaunchKernelGGL(np_shocks_kernel, dim3((unsigned)((n_paths + 63) / 64)), dim3(64), 0, nullptr, io, n_months, rho, rho_c, d);
     } else {
-        hipLaunchKernelGGL(shocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, seed,
+        hipLaunchKernelGGL(shocks_kernel, dim3((unsigned)((n_paths + 63) / 64)), dim3(64), 0, nullptr, seed,
                            stream_id, path_begin, n_paths, n_months, rho, rho_c, d);
     }
     e = hipGetLastError();

@@ -213,22 +213,42 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 #define ORC_TWO_PI 6.283185307179586476925286766559
-/* One shock row (equity, inflation, premium) for (seed, stream, path, month):
- *   x0..x3 = philox; u = (x + 0.5) * 2^-32 in (0,1);
- *   (z0, z1) = sqrt(-2 ln u0) * (cos, sin)(2 pi u1);  z2 = sqrt(-2 ln u2) * cos(2 pi u3);
- *   equity = z0; inflation = rho*z0 + sqrt(max(0, 1-rho^2))*z1; premium = z2  (:459-466). */
-void orc_shock_row(uint64_t seed, uint32_t stream_id, uint64_t path, uint32_t month, double rho,
-                   double out[3]) {
-    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), month, stream_id};
+/*
+ * The path's standard-normal sequence n[0], n[1], ... (engine definition, replaces the NumPy draw):
+ *   pair j = Box-Muller of two Philox words (xr, xa): u = (x + 0.5) 2^-32,
+ *            n[2j] = sqrt(-2 ln u_r) cos(2 pi u_a),  n[2j+1] = sqrt(-2 ln u_r) sin(2 pi u_a);
+ *   pair j takes words 2(j&1), 2(j&1)+1 of Philox block j>>1, counter (path_lo, path_hi, block, stream_id),
+ *   key (seed_lo, seed_hi).
+ * Shock row k (absolute month k+1) = (equity, inflation, premium) =
+ *   (n[3k], rho n[3k] + sqrt(max(0,1-rho^2)) n[3k+1], n[3k+2])          (simulation.py:459-466)
+ * so 4 rows consume exactly 3 Philox blocks = 6 pairs, and row k is a pure function of
+ * (seed, stream, path, k): common random numbers across working-month candidates.
+ */
+static void orc_bm_pair(uint32_t xr, uint32_t xa, double* zc, double* zs) {
+    const double S = 2.3283064365386962890625e-10; /* 2^-32 */
+    double ur = ((double)xr + 0.5) * S, ua = ((double)xa + 0.5) * S;
+    double r = sqrt(-2.0 * log(ur));
+    *zc = r * cos(ORC_TWO_PI * ua);
+    *zs = r * sin(ORC_TWO_PI * ua);
+}
+
+/* n[i] for one path, from scratch */
+double orc_path_normal(uint64_t seed, uint32_t stream_id, uint64_t path, uint64_t i) {
+    uint64_t pair = i >> 1, block = pair >> 1;
+    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)block, stream_id};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4];
+    double zc, zs;
     orc_philox4x32_10(ctr, key, x);
-    const double S = 2.3283064365386962890625e-10; /* 2^-32 */
-    double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
-    double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;
-    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-    double z0 = r0 * cos(ORC_TWO_PI * u1), z1 = r0 * sin(ORC_TWO_PI * u1);
-    double z2 = r1 * cos(ORC_TWO_PI * u3);
+    orc_bm_pair(x[2 * (pair & 1)], x[2 * (pair & 1) + 1], &zc, &zs);
+    return (i & 1) ? zs : zc;
+}
+
+void orc_shock_row(uint64_t seed, uint32_t stream_id, uint64_t path, uint32_t month, double rho,
+                   double out[3]) {
+    double z0 = orc_path_normal(seed, stream_id, path, 3ull * month);
+    double z1 = orc_path_normal(seed, stream_id, path, 3ull * month + 1);
+    double z2 = orc_path_normal(seed, stream_id, path, 3ull * month + 2);
     out[0] = z0;
     out[1] = rho * z0 + sqrt(pymax(0.0, 1.0 - rho * rho)) * z1; /* :461-464 */
     out[2] = z2;
