@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--paths", type=int, default=1_000_000, help="paths per GPU per step")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the HBM-side kernels (trajectory write / quantiles / histogram)")
     ap.add_argument("--aux-paths", type=int, default=4_000_000)
@@ -129,15 +130,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
 
     with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
         cfg = Config(**dict(json.load(fh), seed=12345))
     params = params_from_config(cfg)
     n = args.paths
-    batch = E.DeviceBatch(params, WORKING_MONTHS, n, want="count", device=local_rank)
+    batch = E.DeviceBatch(params, WORKING_MONTHS, n, want="count", device=device)
 
     def step(i):
         # global path index: step-major, then rank (every path of the job is distinct)
