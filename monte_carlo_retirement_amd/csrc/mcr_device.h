@@ -22,7 +22,7 @@ namespace mcr {
 
 constexpr double kEps = MCR_SMALL_EPSILON;
 constexpr int kMPY = MCR_MONTHS_PER_YEAR;
-constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
+constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SIMD (128 measured: no better)
 
 // Per-stream data prepared on the host (mcr_abi: derive_params) from mcr_stream.
 struct DevStream {
@@ -50,6 +50,19 @@ struct DevParams {
     int32_t any_annual_tax;            // annual_rate1 > 0 || annual_rate2 > 0
     DevStream streams[MCR_MAX_STREAMS];
 };
+
+// The four parameters that feed per-lane SELECTS (seller's weight / seller's rate).  They are
+// wave-uniform, but a select between two SGPR pairs costs two v_mov per dword (one constant-bus
+// operand per VALU instruction) and the kernel is already SGPR-bound (57 spills): the path kernel keeps
+// a VGPR-resident copy.
+struct LaneParams {
+    double alloc1, alloc2, real_rate1, real_rate2;
+};
+__device__ __forceinline__ LaneParams lane_params(const DevParams& P) {
+    LaneParams L{P.alloc1, P.alloc2, P.real_rate1, P.real_rate2};
+    asm volatile("" : "+v"(L.alloc1), "+v"(L.alloc2), "+v"(L.real_rate1), "+v"(L.real_rate2));
+    return L;
+}
 
 // ---------------------------------------------------------------------------------------------
 // RNG: Philox4x32-10 (Salmon et al. SC'11, Random123 constants).  Counter = (path_lo, path_hi,
@@ -158,7 +171,7 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
 }
 
 // _rebalance_portfolio (:274-359), branch-free: the over-weight asset is the seller.
-__device__ __forceinline__ void rebalance(const DevParams& P, double& b1, double& c1, double& b2,
+__device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, double& c1, double& b2,
                                           double& c2) {
     const double total = b1 + b2;                                  // :288
     const double drift1 = b1 - total * P.alloc1;                   // :293-294
@@ -198,15 +211,15 @@ __device__ __forceinline__ void rebalance(const DevParams& P, double& b1, double
 }
 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
-__device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, double& b1, double& c1,
+__device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
     if (P.any_annual_tax) {  // wave-uniform: with no annual-tax asset the bill is 0 (:380-390)
         const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
         const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
         const double total_due = due1 + due2;                         // :390
-        const double cap1 = net_liquidation_value(b1, c1, P.real_rate1);  // :392-397
-        const double cap2 = net_liquidation_value(b2, c2, P.real_rate2);  // :398-403
+        const double cap1 = net_liquidation_value(b1, c1, L.real_rate1);  // :392-397
+        const double cap2 = net_liquidation_value(b2, c2, L.real_rate2);  // :398-403
         const double cap = cap1 + cap2;                               // :404
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
@@ -214,12 +227,12 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, double& b1
             const double share1 = fdiv(cap1, cap);                    // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
-            withdraw(b1, c1, pay * share1, P.real_rate1, g, net1);    // :411-419
-            withdraw(b2, c2, pay * share2, P.real_rate2, g, net2);    // :420-428
+            withdraw(b1, c1, pay * share1, L.real_rate1, g, net1);    // :411-419
+            withdraw(b2, c2, pay * share2, L.real_rate2, g, net2);    // :420-428
             tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
         }
     }
-    rebalance(P, b1, c1, b2, c2);  // :432-442 (always)
+    rebalance(L, b1, c1, b2, c2);  // :432-442 (always)
     return tax_failed;
 }
 

@@ -42,10 +42,17 @@ struct KernelIO {
     const uint32_t* path_seeds;  // [n_paths] explicit seeds or nullptr
 };
 
-__device__ __forceinline__ double nan_f64() { return __longlong_as_double(0x7ff8000000000000LL); }
+// NaN OUTPUT values travel as integer bit patterns (robust against any no-NaN math assumption: the
+// state machine itself never produces a NaN for valid scenarios).
+// (YearsToRuin of successful paths, withdrawal rates after failure.)
+constexpr unsigned long long kNanBits = 0x7ff8000000000000ull;
+__device__ __forceinline__ unsigned long long f64_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ void store_bits(double* p, unsigned long long bits) { *reinterpret_cast<unsigned long long*>(p) = bits; }
 
+// __launch_bounds__(256, 4): the kernel saturates the fp64 VALU with 4 waves per SIMD (measured by capping
+// residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.
 template <int MODE, int RNG>
-__global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const KernelIO io) {
+__global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, const KernelIO io) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS: math tables (mcr_math.h), [numpy ziggurat tables], [n_lock_slots][kBlock] doubles (frozen
     // nominal stream amounts), then block counters
@@ -103,6 +110,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
         }
     };
 
+    const LaneParams L = lane_params(P);
+
     // ---- initial state (:490-510) ----
     double b1 = P.initial_balance * P.alloc1;  // :499
     double b2 = P.initial_balance - b1;        // :500
@@ -124,9 +133,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance(P, b1, c1, b2, c2);                                  // :549-553
+        rebalance(L, b1, c1, b2, c2);                                  // :549-553
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes(P, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
     double fy_gross = 0.0, fy_real = 0.0;            // :623-624
     bool alive = !pre_fail;                          // :627, :633
     bool succeeded = !pre_fail;
-    double years_to_ruin = pre_fail ? 0.0 : nan_f64();  // :497, :628-629
+    unsigned long long ytr_bits = pre_fail ? f64_bits(0.0) : kNanBits;  // YearsToRuin (:497, :628-629)
     int ruin_bin = pre_fail ? 0 : -1;
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
@@ -182,23 +191,23 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
                     }
                 }
                 if (!stop) {
-                    const double cap1 = net_liquidation_value(b1, c1, P.real_rate1);  // :726-731
-                    const double cap2 = net_liquidation_value(b2, c2, P.real_rate2);  // :732-737
+                    const double cap1 = net_liquidation_value(b1, c1, L.real_rate1);  // :726-731
+                    const double cap2 = net_liquidation_value(b2, c2, L.real_rate2);  // :732-737
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmax(0.0, fmin(need, cap));                 // :739-742
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
                     const double prop1 = cap > kEps ? fdiv(cap1, cap) : P.alloc1;     // :750-754
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
-                    withdraw(b1, c1, target * prop1, P.real_rate1, gw1, nw1);         // :757-765
+                    withdraw(b1, c1, target * prop1, L.real_rate1, gw1, nw1);         // :757-765
                     tg1 += gw1;                                                       // :766
-                    withdraw(b2, c2, target * prop2, P.real_rate2, gw2, nw2);         // :768-776
+                    withdraw(b2, c2, target * prop2, L.real_rate2, gw2, nw2);         // :768-776
                     tg2 += gw2;                                                       // :777
                     if (kSummary) treal += fdiv((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance(P, b1, c1, b2, c2);                                     // :792-796
+                    rebalance(L, b1, c1, b2, c2);                                     // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
-                        const bool tf = annual_gain_taxes(P, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        const bool tf = annual_gain_taxes(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
                         yfail = yfail || tf;                                          // :821-822
                     }
@@ -207,37 +216,38 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
             }
         }
         // ---- year end (:830-868); lanes that were already dead pad with 0 / NaN (:902-916,:934-935) ----
-        double sample = 0.0, wr = nan_f64();
+        double sample = 0.0;
+        unsigned long long wr_bits = kNanBits;
         if (alive) {
             const double ygw = tg1 + tg2;                                              // :830-832
             const double wr_pct = start_balance > kEps ? (treal / start_balance) * 100.0 : 0.0;  // :834-840
             if (year == 0) { fy_gross = ygw; fy_real = treal; }                        // :852-856, :861-865
             if (yfail) {
                 succeeded = false;                                                     // :843
-                years_to_ruin = (double)(fail_rmi + 1) / (double)kMPY;                 // :825-827, :844-847
+                ytr_bits = f64_bits((double)(fail_rmi + 1) / (double)kMPY);            // :825-827, :844-847
                 ruin_bin = 1 + year;
                 sample = fmax(0.0, b1 + b2);                                           // :848
                 alive = false;                                                         // :857
             } else {
-                wr = wr_pct;                                                           // :859
+                wr_bits = f64_bits(wr_pct);                                            // :859
                 sample = b1 + b2;                                                      // :867
                 done_years = year + 1;
             }
         }
         put_sample(t_idx, sample, infl);  // dead lanes: 0 / px = 0 (:906-916, :928-931)
         ++t_idx;
-        if (kTraj && valid && wrt) wrt[(int64_t)year * stride + (int64_t)li] = wr;  // :851, :859, :934-935
+        if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], wr_bits);  // :851, :859, :934-935
     }
     for (; year < ry; ++year) {  // the whole wave failed early: pad (:902-916, :934-935)
         put_sample(t_idx++, 0.0, infl);
-        if (kTraj && valid && wrt) wrt[(int64_t)year * stride + (int64_t)li] = nan_f64();
+        if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], kNanBits);
     }
 
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes(P, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
-            if (tf) { succeeded = false; years_to_ruin = (double)ry; ruin_bin = ry + 1; }  // :894-896
+            const bool tf = annual_gain_taxes(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            if (tf) { succeeded = false; ytr_bits = f64_bits((double)ry); ruin_bin = ry + 1; }  // :894-896
             put_sample(P.trajectory_len - 1, b1 + b2, infl);                     // :897-898
         }
     }
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const DevParams P, const K
         const mcr_outputs& o = io.out;
         if (o.start_balance) o.start_balance[li] = start_balance;
         if (o.final_balance) o.final_balance[li] = final_balance;
-        if (o.years_to_ruin) o.years_to_ruin[li] = years_to_ruin;
+        if (o.years_to_ruin) store_bits(&o.years_to_ruin[li], ytr_bits);
         if (o.first_year_gross_withdrawal) o.first_year_gross_withdrawal[li] = fy_gross;
         if (o.first_year_real_gross_withdrawal) o.first_year_real_gross_withdrawal[li] = fy_real;
         if (o.inflation_at_retirement) o.inflation_at_retirement[li] = infl_ret;
@@ -311,14 +321,14 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
         case MCR_HELPER_REBALANCE: {
             const double* x = in + 4 * i;
             double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
-            rebalance(P, b1, c1, b2, c2);
+            rebalance(lane_params(P), b1, c1, b2, c2);
             out[4 * i + 0] = b1; out[4 * i + 1] = c1; out[4 * i + 2] = b2; out[4 * i + 3] = c2;
             break;
         }
         case MCR_HELPER_ANNUAL_TAX: {
             const double* x = in + 6 * i;
             double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
-            const bool tf = annual_gain_taxes(P, b1, c1, b2, c2, x[4], x[5]);
+            const bool tf = annual_gain_taxes(P, lane_params(P), b1, c1, b2, c2, x[4], x[5]);
             out[5 * i + 0] = b1; out[5 * i + 1] = c1; out[5 * i + 2] = b2; out[5 * i + 3] = c2;
             out[5 * i + 4] = tf ? 1.0 : 0.0;
             break;
