@@ -224,6 +224,20 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
  * digit histograms and a per-row candidate buffer of n/64 + 4096 keys); 0 = unsupported shape.
  */
 int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n);
+/*
+ * The same selection as separate steps, for rows SHARDED across GPUs (each rank holds n_local of the
+ * n_total entries of every row): begin once, then for pass = 0..7: hist (rank-local digit histograms;
+ * pass 3 also compacts candidates) -> the caller sums the dense 32-bit counter block of the scratch
+ * buffer across ranks (byte offset / word count from mcr_row_quantiles_reduce_block; one small
+ * all-reduce per pass, the trajectories themselves never move) -> scan (identical on every rank).
+ * After pass 7, `out`/`counts` hold the exact global quantiles on every rank.
+ */
+int64_t mcr_row_quantiles_reduce_block(int32_t n_rows, int64_t* n_words);
+int mcr_row_quantiles_begin(void* scratch, int32_t n_rows, int device, void* hip_stream);
+int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
+                           int32_t pass, void* scratch, int device, void* hip_stream);
+int mcr_row_quantiles_scan(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
+                           uint64_t* counts, void* scratch, int device, void* hip_stream);
 int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n,
                       const double* q, int32_t n_q, double* out, uint64_t* counts,
                       void* scratch, int device, void* hip_stream);

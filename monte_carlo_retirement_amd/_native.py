@@ -164,6 +164,10 @@ ABI_SYMBOLS = (
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
+    "mcr_row_quantiles_reduce_block",
+    "mcr_row_quantiles_begin",
+    "mcr_row_quantiles_hist",
+    "mcr_row_quantiles_scan",
     "mcr_minmax_success",
     "mcr_histogram_success",
 )
@@ -228,6 +232,18 @@ def _declare(lib: C.CDLL) -> None:
     lib.mcr_row_quantiles.argtypes = [
         C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+    ]
+    lib.mcr_row_quantiles_reduce_block.restype = C.c_int64
+    lib.mcr_row_quantiles_reduce_block.argtypes = [C.c_int32, P(C.c_int64)]
+    lib.mcr_row_quantiles_begin.restype = C.c_int
+    lib.mcr_row_quantiles_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
+    lib.mcr_row_quantiles_hist.restype = C.c_int
+    lib.mcr_row_quantiles_hist.argtypes = [
+        C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_void_p,
+    ]
+    lib.mcr_row_quantiles_scan.restype = C.c_int
+    lib.mcr_row_quantiles_scan.argtypes = [
+        C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
     ]
     lib.mcr_minmax_success.restype = C.c_int
     lib.mcr_minmax_success.argtypes = [

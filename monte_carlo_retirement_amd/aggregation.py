@@ -26,13 +26,22 @@ def _pandas_q(qs: Sequence[float]) -> np.ndarray:
     return np.true_divide(np.asarray(qs, dtype=np.float64) * 100.0, 100)
 
 
-def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0, reduce_counts=None,
+                  n_total: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
     """Quantiles of each row of a device tensor ``rows[n_rows, stride]`` over its first ``n``
     entries, NaNs skipped — ``DataFrame(rows.T).quantile(qs, axis=0)`` semantics.
+
+    Multi-GPU: when every rank holds ``n`` of the ``n_total`` entries of each row, pass
+    ``reduce_counts`` (a callable that sums an int32 tensor across ranks in place, e.g.
+    ``distributed.all_reduce_sum_``): the digit histograms are summed after every pass and every
+    rank returns the exact GLOBAL quantiles; the rows themselves never leave their GPU.
 
     Returns ``(q[n_rows, len(qs)], non_nan_counts[n_rows])`` as numpy arrays.
     """
     import torch
+
+    if reduce_counts is not None:
+        return _row_quantiles_sharded(rows, int(n), qs, reduce_counts, int(n_total if n_total is not None else n))
 
     assert rows.is_cuda and rows.dtype == torch.float64 and rows.dim() == 2 and rows.stride(1) == 1
     lib = N.load_library()
@@ -51,6 +60,35 @@ def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0) -> Tuple[n
         out.data_ptr(), counts.data_ptr(), scratch.data_ptr(), dev.index or 0, C.c_void_p(stream),
     )
     N.check(rc, "mcr_row_quantiles")
+    return out.cpu().numpy(), counts.cpu().numpy()
+
+
+def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int):
+    import torch
+
+    assert rows.is_cuda and rows.dtype == torch.float64 and rows.dim() == 2 and rows.stride(1) == 1
+    lib = N.load_library()
+    n_rows = int(rows.shape[0])
+    q = _pandas_q(qs)
+    dev = rows.device
+    di = dev.index or 0
+    out = torch.empty((n_rows, len(q)), dtype=torch.float64, device=dev)
+    counts = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+    nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q), n_local))
+    if nbytes <= 0:
+        raise ValueError("unsupported number of rows / quantiles")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    n_words = C.c_int64()
+    off = int(lib.mcr_row_quantiles_reduce_block(n_rows, C.byref(n_words)))
+    block = scratch[off:off + 4 * n_words.value].view(torch.int32)  # the dense counter block to sum across ranks
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    N.check(lib.mcr_row_quantiles_begin(scratch.data_ptr(), n_rows, di, stream), "mcr_row_quantiles_begin")
+    for p in range(8):
+        N.check(lib.mcr_row_quantiles_hist(rows.data_ptr(), int(rows.stride(0)), n_rows, n_local, len(q), p,
+                                           scratch.data_ptr(), di, stream), "mcr_row_quantiles_hist")
+        reduce_counts(block)
+        N.check(lib.mcr_row_quantiles_scan(n_rows, n_total, q.ctypes.data, len(q), p, out.data_ptr(), counts.data_ptr(),
+                                           scratch.data_ptr(), di, stream), "mcr_row_quantiles_scan")
     return out.cpu().numpy(), counts.cpu().numpy()
 
 

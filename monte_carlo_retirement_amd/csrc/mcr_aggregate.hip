@@ -26,16 +26,18 @@ constexpr int kRqBlock = 256;
 
 struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
     unsigned long long n_valid;          // non-NaN entries (= wr_df.count(axis=1) for WR rows)
-    unsigned long long nan_count;
     unsigned long long rank[kRqMaxT];    // remaining rank of target t inside its group's prefix
     unsigned long long prefix[kRqMaxT];  // key prefix of group g (high 8*pass bits)
     double value[kRqMaxT];               // selected order statistic of target t (after the last pass)
     double gamma[kRqMaxQ];               // interpolation weight of quantile j
     int group_of[kRqMaxT];
     int n_targets, n_groups;
-    unsigned int cand_count;             // keys appended to the candidate buffer in pass 3
-    unsigned int overflow;               // 1 if they did not fit (row falls back to full passes)
+    unsigned int cand_count;             // keys appended to the (rank-local) candidate buffer in pass 3
+    unsigned int pad_;
 };
+// Scratch layout: RqRow[n_rows] | hist u32[n_rows][kRqMaxT][256] | aux u32[n_rows][2] | cand u64[n_rows][cap].
+// hist|aux is ONE dense block of 32-bit counters: a multi-GPU caller sums it across ranks after every
+// histogram step (aux[r][0] = NaN count, aux[r][1] = #ranks whose candidate buffer overflowed).
 
 struct RqArgs {
     double q[kRqMaxQ];
@@ -75,8 +77,8 @@ __device__ __forceinline__ void hist_add_aggregated(unsigned int* lh, bool activ
 template <bool FIRST, bool COMPACT>
 __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restrict__ rows, int64_t row_stride,
                                                           int64_t n, int pass, RqRow* st, unsigned int* hist,
-                                                          unsigned long long* cand, unsigned int cand_cap,
-                                                          int only_overflowed) {
+                                                          unsigned int* aux, unsigned long long* cand,
+                                                          unsigned int cand_cap, int only_overflowed) {
     extern __shared__ __align__(16) unsigned int lh[];  // [max groups of this call][256], sized by the host
     __shared__ unsigned long long lpref[kRqMaxT];
     __shared__ unsigned int lnan;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     __shared__ unsigned long long stage[COMPACT ? kStage : 1];
     __shared__ unsigned int stage_n, stage_base;
     const int row = blockIdx.y;
-    if (only_overflowed && !st[row].overflow) return;  // slow path only for rows whose candidates overflowed
+    if (only_overflowed && !aux[2 * row + 1]) return;  // slow path only for rows whose candidates overflowed
     const int G = FIRST ? 1 : st[row].n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     unsigned int* gh = hist + (size_t)row * kRqMaxT * 256;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock)
         if (lh[k]) atomicAdd(&gh[k], lh[k]);
-    if (FIRST && threadIdx.x == 0 && lnan) atomicAdd(&st[row].nan_count, (unsigned long long)lnan);
+    if (FIRST && threadIdx.x == 0 && lnan) atomicAdd(&aux[2 * row], lnan);
     if (COMPACT) {  // flush the stage: one global reservation per workgroup, coalesced copy
         const unsigned int cnt = stage_n < (unsigned int)kStage ? stage_n : (unsigned int)kStage;
         if (threadIdx.x == 0) stage_base = cnt ? atomicAdd(&st[row].cand_count, cnt) : 0u;
@@ -183,12 +185,13 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
 // Passes 4..7 over the compacted candidate keys of one row (one workgroup per row; the candidates
 // are a few thousand keys, L2-resident).  Rows whose candidates overflowed are left to the slow path.
 __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow* st, unsigned int* hist,
+                                                               const unsigned int* aux,
                                                                const unsigned long long* cand, unsigned int cand_cap) {
     extern __shared__ __align__(16) unsigned int lh[];
     __shared__ unsigned long long lpref[kRqMaxT];
     const int row = blockIdx.y;
     RqRow& S = st[row];
-    if (S.overflow) return;
+    if (aux[2 * row + 1]) return;
     const int G = S.n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = S.prefix[threadIdx.x];
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow*
 // interpolate (NumPy `linear`) and write the quantiles.
 __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                     const RqArgs args, double* out, unsigned long long* counts,
-                                                    unsigned int cand_cap) {
+                                                    unsigned int* aux) {
     __shared__ unsigned long long new_prefix[kRqMaxT];
     extern __shared__ __align__(16) unsigned int sh[];  // this row's histograms, [n_groups][256]
     const int row = blockIdx.x;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
         for (int k = t; k < ng * 256; k += 64) sh[k] = gh[k];
     }
     if (pass == 0 && t == 0) {
-        const unsigned long long m = (unsigned long long)n - S.nan_count;
+        const unsigned long long m = (unsigned long long)n - (unsigned long long)aux[2 * row];
         S.n_valid = m;
         if (counts) counts[row] = m;
         int nt = 0;
@@ -281,7 +284,6 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
         S.n_groups = ng > 0 ? ng : 1;
     }
     for (int k = t; k < old_groups * 256; k += 64) gh[k] = 0u;  // ready for the next pass / call
-    if (pass == 3 && t == 0) S.overflow = S.cand_count > cand_cap ? 1u : 0u;
     __syncthreads();
     if (pass == 7) {
         if (t < nt) S.value[t] = value_of(new_prefix[t]);
@@ -301,14 +303,20 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
     }
 }
 
+// after the compaction pass: did this rank's candidate buffer overflow for the row?
+__global__ void rq_flag_kernel(const RqRow* st, unsigned int* aux, int n_rows, unsigned int cand_cap) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) aux[2 * r + 1] = st[r].cand_count > cand_cap ? 1u : 0u;
+}
+
 __global__ void rq_init_kernel(RqRow* st, unsigned int* hist, int n_rows) {
-    const size_t total = (size_t)n_rows * kRqMaxT * 256;
+    const size_t total = (size_t)n_rows * kRqMaxT * 256 + (size_t)n_rows * 2;  // hist | aux
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x)
         hist[k] = 0u;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_rows) {
-        st[r].nan_count = 0ull; st[r].n_valid = 0ull; st[r].n_targets = 0; st[r].n_groups = 1; st[r].prefix[0] = 0ull;
-        st[r].cand_count = 0u; st[r].overflow = 0u;
+        st[r].n_valid = 0ull; st[r].n_targets = 0; st[r].n_groups = 1; st[r].prefix[0] = 0ull;
+        st[r].cand_count = 0u;
     }
 }
 
@@ -398,67 +406,132 @@ static int grid_for(int64_t n, int per_block, int cap) {
     return (int)b;
 }
 
-}  // namespace mcr
-
-using namespace mcr;
-
-extern "C" {
-
 static unsigned int rq_cand_cap(int64_t n) { return (unsigned int)(n / 64 + 4096); }
 
-int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n) {
-    if (n_rows <= 0 || n_q <= 0 || n_q > kRqMaxQ || n <= 0 || n >= ((int64_t)1 << 32)) return 0;
-    return (int64_t)n_rows * (int64_t)(sizeof(RqRow) + (size_t)kRqMaxT * 256 * sizeof(unsigned int) +
-                                      (size_t)rq_cand_cap(n) * sizeof(unsigned long long));
+struct RqLayout {
+    RqRow* st;
+    unsigned int* hist;
+    unsigned int* aux;
+    unsigned long long* cand;
+    size_t reduce_offset, reduce_words;
+};
+static RqLayout rq_layout(void* scratch, int32_t n_rows) {
+    RqLayout L;
+    char* base = (char*)scratch;
+    L.st = (RqRow*)base;
+    L.reduce_offset = (size_t)n_rows * sizeof(RqRow);
+    L.hist = (unsigned int*)(base + L.reduce_offset);
+    L.reduce_words = (size_t)n_rows * kRqMaxT * 256 + (size_t)n_rows * 2;
+    L.aux = L.hist + (size_t)n_rows * kRqMaxT * 256;
+    L.cand = (unsigned long long*)(L.hist + ((L.reduce_words + 1) & ~(size_t)1));  // 8-byte aligned
+    return L;
 }
 
-int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q,
-                      int32_t n_q, double* out, uint64_t* counts, void* scratch, int device, void* hip_stream) {
+static int rq_check(const void* scratch, int32_t n_rows, int64_t n_local, int32_t n_q) {
+    if (!scratch || n_rows <= 0 || n_rows > 65535 || n_q <= 0 || n_q > kRqMaxQ) { set_error("bad row-quantile arguments"); return MCR_ERR_INVALID_ARG; }
+    if (n_local < 0 || n_local >= ((int64_t)1 << 32)) { set_error("n must be < 2^32 per row"); return MCR_ERR_INVALID_ARG; }
+    return MCR_OK;
+}
+
+}  // namespace mcr
+using namespace mcr;
+extern "C" {
+
+int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n) {
+    if (n_rows <= 0 || n_q <= 0 || n_q > kRqMaxQ || n < 0 || n >= ((int64_t)1 << 32)) return 0;
+    const size_t words = (size_t)n_rows * kRqMaxT * 256 + (size_t)n_rows * 2;
+    return (int64_t)((size_t)n_rows * sizeof(RqRow) + ((words + 1) & ~(size_t)1) * sizeof(unsigned int) +
+                     (size_t)n_rows * (size_t)rq_cand_cap(n) * sizeof(unsigned long long));
+}
+
+int64_t mcr_row_quantiles_reduce_block(int32_t n_rows, int64_t* n_words) {
+    if (n_rows <= 0) return -1;
+    if (n_words) *n_words = (int64_t)n_rows * kRqMaxT * 256 + (int64_t)n_rows * 2;
+    return (int64_t)((size_t)n_rows * sizeof(RqRow));
+}
+
+int mcr_row_quantiles_begin(void* scratch, int32_t n_rows, int device, void* hip_stream) {
     int rc = use_device(device);
     if (rc != MCR_OK) return rc;
-    if (!rows || !q || !out || !scratch || n_rows <= 0 || n <= 0 || n_q <= 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
-    if (n_q > kRqMaxQ) { set_error("at most %d quantiles per call", kRqMaxQ); return MCR_ERR_INVALID_ARG; }
-    if (row_stride < n) { set_error("row_stride < n"); return MCR_ERR_INVALID_ARG; }
-    if (n >= ((int64_t)1 << 32)) { set_error("n must be < 2^32 per row"); return MCR_ERR_INVALID_ARG; }
-    if (n_rows > 65535) { set_error("too many rows"); return MCR_ERR_INVALID_ARG; }
+    rc = rq_check(scratch, n_rows, 0, 1);
+    if (rc != MCR_OK) return rc;
+    const RqLayout L = rq_layout(scratch, n_rows);
+    hipLaunchKernelGGL(rq_init_kernel, dim3(grid_for((int64_t)L.reduce_words, 256, 1024)), dim3(256), 0, (hipStream_t)hip_stream,
+                       L.st, L.hist, n_rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rq_init_kernel");
+    return MCR_OK;
+}
+
+int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
+                           int32_t pass, void* scratch, int device, void* hip_stream) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    rc = rq_check(scratch, n_rows, n_local, n_q);
+    if (rc != MCR_OK) return rc;
+    if (pass < 0 || pass > 7) { set_error("pass out of range"); return MCR_ERR_INVALID_ARG; }
+    if (n_local > 0 && (!rows || row_stride < n_local)) { set_error("bad rows / row_stride"); return MCR_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    const RqLayout L = rq_layout(scratch, n_rows);
+    const unsigned int cap = rq_cand_cap(n_local);
+    const int64_t n = n_local;
+    if (n > 0) {
+        // each workgroup streams >= 16 elements per lane; ~4096 workgroups in flight fill the 256 CUs
+        int bx = grid_for(n, kRqBlock * 16, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
+        const dim3 grid(bx, n_rows), block(kRqBlock);
+        // rows whose candidates overflowed (big ties, e.g. the all-equal t=0 row) re-stream alone: give each
+        // row a wide grid; workgroups of the other rows exit at once
+        const dim3 grid_slow(grid_for(n, kRqBlock * 16, 1024), n_rows);
+        const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);  // <= 2 targets per quantile
+        const size_t lds_first = 256 * sizeof(unsigned int);
+        if (pass == 0) {
+            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0);
+        } else if (pass < 3) {
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0);
+        } else if (pass == 3) {
+            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0);
+        } else {
+            hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, n_rows), block, lds_groups, s, pass, L.st, L.hist, L.aux, L.cand, cap);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1);
+        }
+    }
+    if (pass == 3) hipLaunchKernelGGL(rq_flag_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, L.st, L.aux, n_rows, cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "row quantile histogram step");
+    return MCR_OK;
+}
+
+int mcr_row_quantiles_scan(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
+                           uint64_t* counts, void* scratch, int device, void* hip_stream) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    rc = rq_check(scratch, n_rows, 0, n_q);
+    if (rc != MCR_OK) return rc;
+    if (!q || !out || pass < 0 || pass > 7 || n_total <= 0 || n_total >= ((int64_t)1 << 32)) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     for (int j = 0; j < n_q; ++j)
         if (!(q[j] >= 0.0 && q[j] <= 1.0)) { set_error("quantile %d out of [0,1]", j); return MCR_ERR_INVALID_ARG; }
-    hipStream_t s = (hipStream_t)hip_stream;
-    const unsigned int cap = rq_cand_cap(n);
-    RqRow* st = (RqRow*)scratch;
-    unsigned int* hist = (unsigned int*)((char*)scratch + (size_t)n_rows * sizeof(RqRow));
-    unsigned long long* cand = (unsigned long long*)((char*)hist + (size_t)n_rows * kRqMaxT * 256 * sizeof(unsigned int));
+    const RqLayout L = rq_layout(scratch, n_rows);
     RqArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
-    hipLaunchKernelGGL(rq_init_kernel, dim3(grid_for((int64_t)n_rows * kRqMaxT * 256, 256, 1024)), dim3(256), 0, s, st, hist, n_rows);
-    // each workgroup streams >= 16 elements per lane; ~4096 workgroups in flight fill the 256 CUs
-    int bx = grid_for(n, kRqBlock * 16, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
-    if (bx < 1) bx = 1;
-    const dim3 grid(bx, n_rows), block(kRqBlock);
-    // rows whose candidates overflowed (big ties, e.g. the all-equal t=0 row) re-stream alone: give each
-    // row a wide grid; workgroups of the other rows exit at once
-    const dim3 grid_slow(grid_for(n, kRqBlock * 16, 1024), n_rows);
-    unsigned long long* cnt = (unsigned long long*)counts;
-    const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);  // <= 2 targets per quantile
-    const size_t lds_first = 256 * sizeof(unsigned int);
-    for (int pass = 0; pass < 8; ++pass) {
-        if (pass == 0) {
-            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, st, hist, cand, cap, 0);
-        } else if (pass < 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, st, hist, cand, cap, 0);
-        } else if (pass == 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, st, hist, cand, cap, 0);
-        } else {
-            hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, n_rows), block, lds_groups, s, pass, st, hist, cand, cap);
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, st, hist, cand, cap, 1);
-        }
-        hipLaunchKernelGGL(rq_scan_kernel, dim3(n_rows), dim3(64), lds_groups, s, n, pass, st, hist, a, out, cnt, cap);
-    }
+    const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);
+    hipLaunchKernelGGL(rq_scan_kernel, dim3(n_rows), dim3(64), lds_groups, (hipStream_t)hip_stream, n_total, pass, L.st, L.hist, a, out,
+                       (unsigned long long*)counts, L.aux);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "row quantile kernels");
+    if (e != hipSuccess) return hip_fail(e, "rq_scan_kernel");
     return MCR_OK;
+}
+
+int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q,
+                      int32_t n_q, double* out, uint64_t* counts, void* scratch, int device, void* hip_stream) {
+    if (!rows || n <= 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
+    int rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+    for (int pass = 0; pass < 8 && rc == MCR_OK; ++pass) {
+        rc = mcr_row_quantiles_hist(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream);
+        if (rc == MCR_OK) rc = mcr_row_quantiles_scan(n_rows, n, q, n_q, pass, out, counts, scratch, device, hip_stream);
+    }
+    return rc;
 }
 
 int mcr_minmax_success(const double* values, const uint8_t* success, int64_t n, double* minmax, int device, void* hip_stream) {

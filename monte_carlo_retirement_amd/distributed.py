@@ -126,3 +126,53 @@ def gpu_count_runner(params, seed: int, stream_id: int, working_months: int, dev
                 "ruin_year_bins": batch.ruin_year_bins.cpu().numpy()}
 
     return run
+
+
+def sharded_row_quantiles(rows, n_local: int, qs):
+    """Exact GLOBAL row quantiles when every rank holds ``n_local`` entries of each row: the radix
+    select's digit histograms are summed across ranks after every pass (8 small all-reduces); the
+    rows never move.  Every rank returns the same ``(quantiles, non_nan_counts)``."""
+    import torch
+
+    from . import aggregation as A
+
+    if not is_active():
+        return A.row_quantiles(rows, n_local, qs)
+    tot = torch.tensor([int(n_local)], dtype=torch.int64, device=_comm_device())
+    all_reduce_sum_(tot)
+    return A.row_quantiles(rows, n_local, qs, reduce_counts=all_reduce_sum_, n_total=int(tot.item()))
+
+
+def run_sharded_bands(params, rng_or_seed, stream_id: int, n_total: int, working_months: int, n_bins: int = 100):
+    """BASELINE configs[2]/[3] on N GPUs: every rank simulates its shard of the global path range with
+    full trajectory output kept in its own HBM; counters and histogram bins are summed, the histogram
+    range is min/max-reduced, and the quantile bands come from the distributed radix select.  Returns
+    the same dict on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    from . import aggregation as A
+    from . import engine as E
+
+    rank, world = (dist.get_rank(), dist.get_world_size()) if is_active() else (0, 1)
+    begin, count = shard_range(int(n_total), rank, world)
+    dev = torch.cuda.current_device()
+    batch = E.DeviceBatch(params, working_months, max(count, 1), want="full", device=dev)
+    if count > 0:
+        batch.launch(rng_or_seed, stream_id, begin, count)
+    ry = batch.sizes.retirement_years
+    vec = torch.cat([batch.counters, batch.wr_obs_counts, batch.ruin_year_bins])
+    if world > 1:
+        all_reduce_sum_(vec)
+    red = unpack_counts(vec.cpu().numpy(), ry)
+    out = {"counts": red, "shard": (begin, count)}
+    out["trajectory_q"], _ = sharded_row_quantiles(batch.trajectory, count, A.TRAJECTORY_QUANTILES)
+    out["real_trajectory_q"], _ = sharded_row_quantiles(batch.real_trajectory, count, A.TRAJECTORY_QUANTILES)
+    out["wr_q"], out["wr_counts"] = sharded_row_quantiles(batch.withdrawal_rate_trajectory, count, A.WR_QUANTILES)
+    fb, ok = batch.summary["final_balance"][:max(count, 0)], batch.success[:max(count, 0)]
+    out["hist_bins"], out["hist_edges"] = A.success_histogram(
+        fb, ok, n_bins,
+        reduce_range=all_reduce_minmax_ if world > 1 else None,
+        reduce_bins=all_reduce_sum_ if world > 1 else None,
+    )
+    return out

@@ -1,0 +1,76 @@
+"""Worker for tests/test_distributed_gpu.py: one rank of a gloo group; all ranks share the box's GPU.
+Checks the product's sharded paths on real kernels: distributed exact quantiles vs pandas on the
+unsharded slab, and run_sharded_bands vs a single-process run of the whole path range."""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.distributed as dist
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, REPO)
+
+from monte_carlo_retirement_amd import Config, params_from_config  # noqa: E402
+from monte_carlo_retirement_amd import aggregation as A  # noqa: E402
+from monte_carlo_retirement_amd import distributed as D  # noqa: E402
+from monte_carlo_retirement_amd import engine as E  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    res = {"rank": rank}
+
+    # ---- (1) distributed quantiles on a synthetic slab (same data on every rank, each takes its shard)
+    rng = np.random.default_rng(77)
+    n_total = 60_001
+    slab = np.empty((6, n_total))
+    slab[0] = rng.lognormal(13, 1, n_total)
+    slab[1] = np.where(rng.random(n_total) < 0.4, np.nan, rng.normal(5, 2, n_total))
+    slab[2] = np.where(rng.random(n_total) < 0.65, 0.0, rng.lognormal(10, 2, n_total))  # giant tie: overflow path
+    slab[3] = 60000.0                                                                     # all equal
+    slab[4] = np.nan                                                                      # all NaN
+    slab[5] = -rng.lognormal(3, 2, n_total)
+    begin, count = D.shard_range(n_total, rank, world)
+    stride = (count + 63) // 64 * 64
+    local = torch.full((6, max(stride, 64)), 7.0, dtype=torch.float64, device="cuda")
+    local[:, :count] = torch.as_tensor(slab[:, begin:begin + count], device="cuda")
+    got, counts = D.sharded_row_quantiles(local, count, A.TRAJECTORY_QUANTILES)
+    exp = pd.DataFrame(slab.T).quantile(list(A.TRAJECTORY_QUANTILES), axis=0).T.to_numpy()
+    res["quantiles_equal"] = bool(np.array_equal(got, exp, equal_nan=True))
+    res["counts_equal"] = counts.tolist() == (~np.isnan(slab)).sum(axis=1).tolist()
+
+    # ---- (2) sharded bands vs one process over the whole range
+    with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
+        cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3, initial_balance=20000.0, monthly_contribution=3000.0))
+    p = params_from_config(cfg)
+    n_paths, wm = 5003, 40
+    sh = D.run_sharded_bands(p, 2024, 1, n_paths, wm, n_bins=60)
+    whole = E.DeviceBatch(p, wm, n_paths, want="full", device=0)
+    whole.launch(2024, 1, 0)
+    tq, _ = A.row_quantiles(whole.trajectory, n_paths, A.TRAJECTORY_QUANTILES)
+    rq, _ = A.row_quantiles(whole.real_trajectory, n_paths, A.TRAJECTORY_QUANTILES)
+    wq, wc = A.row_quantiles(whole.withdrawal_rate_trajectory, n_paths, A.WR_QUANTILES)
+    hb, he = A.success_histogram(whole.summary["final_balance"], whole.success, 60)
+    res["bands_equal"] = bool(np.array_equal(sh["trajectory_q"], tq, equal_nan=True) and np.array_equal(sh["real_trajectory_q"], rq, equal_nan=True)
+                              and np.array_equal(sh["wr_q"], wq, equal_nan=True) and sh["wr_counts"].tolist() == wc.tolist())
+    res["hist_equal"] = bool(sh["hist_bins"].tolist() == hb.tolist() and np.array_equal(sh["hist_edges"], he))
+    res["counts_ok"] = bool(sh["counts"].success == int(whole.counters[0].item()) and sh["counts"].paths == n_paths
+                            and sh["counts"].ruin_year_bins.tolist() == whole.ruin_year_bins.cpu().tolist())
+    res["success"] = sh["counts"].success
+    with open(f"{out_path}.{rank}", "w") as fh:
+        json.dump(res, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

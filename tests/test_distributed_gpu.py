@@ -1,0 +1,43 @@
+"""Multi-rank paths on real kernels: 2 and 3 ranks of a gloo group share the box's single GPU
+(the 8-GPU RCCL run is the driver's).  Distributed exact quantiles and sharded bands must be
+bit-identical to the unsharded computation."""
+
+from __future__ import annotations
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_quantiles_and_bands_equal_unsharded(tmp_path, world):
+    out = str(tmp_path / "res")
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                   LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_gpu_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        stdout, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, stdout.decode()[-3000:]
+    res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    for r in res:
+        assert r["quantiles_equal"] and r["counts_equal"], r
+        assert r["bands_equal"] and r["hist_equal"] and r["counts_ok"], r
+        assert r["success"] == res[0]["success"]
