@@ -176,6 +176,9 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     const double total = b1 + b2;                                  // :288
     const double drift1 = b1 - total * P.alloc1;                   // :293-294
     const bool act = (total > kEps) && (fabs(drift1) > kEps);      // :290-296
+    // Wave-uniform early-out: the rebalance that closes the yearly tax step runs right after the monthly
+    // one, when every lane is already within eps of its target (nothing to do for the whole wave).
+    if (__ballot(act) == 0ull) return;
     const bool sell1 = drift1 > 0.0;                               // :298
     const double drift2 = b2 - total * P.alloc2;                   // :328
     const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;       // seller
