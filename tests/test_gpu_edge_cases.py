@@ -1,0 +1,104 @@
+"""Edge cases of the path on the GPU vs the oracle: maximum stream count (all LDS lock slots in use),
+very long horizons, degenerate scenarios, ragged batch sizes, argument errors."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from monte_carlo_retirement_amd import Config, params_from_config
+from monte_carlo_retirement_amd import _native as N
+from monte_carlo_retirement_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+REL, ABS = 1e-9, 1e-6
+
+
+def _base(**over):
+    d = dict(load_golden("helpers.json")["tax_cfgs"][5])
+    d.update(over)
+    return d
+
+
+def _check(oracle, cfgd, wm, n=300, seed=11, stream=1, begin=0):
+    p = params_from_config(Config(**cfgd))
+    g = E.run_batch_host(p, seed, stream, begin, n, wm)
+    c = oracle.run_batch(p, seed, stream, begin, n, wm)
+    assert np.array_equal(g["success"], c["success"])
+    assert g["counters"].tolist() == c["counters"].tolist()
+    assert g["ruin_year_bins"].tolist() == c["ruin_year_bins"].tolist()
+    assert g["wr_obs_counts"].tolist() == c["wr_obs_counts"].tolist()
+    for k in E.SUMMARY_FIELDS + ("trajectory", "real_trajectory", "withdrawal_rate_trajectory"):
+        np.testing.assert_allclose(g[k], c[k], rtol=REL, atol=ABS, equal_nan=True, err_msg=k)
+    return g
+
+
+def _stream(i, indexed, dur, age, amount=300.0, tax=0.1):
+    return {"name": f"s{i}", "monthly_amount_today": amount, "start_at_age": age, "duration_years": dur,
+            "inflation_indexed": indexed, "tax_rate": tax}
+
+
+def test_sixteen_streams_all_kinds(oracle):
+    """MCR_MAX_STREAMS streams: 11 non-indexed (11 LDS lock columns), finite / zero / infinite durations,
+    start ages before, at and long after retirement, overlapping windows."""
+    streams = [_stream(i, indexed=(i % 3 == 0), dur=[None, 0, 1, 3, 7][i % 5], age=38.0 + 1.75 * i, amount=150.0 + 40 * i, tax=0.05 * (i % 4))
+               for i in range(16)]
+    cfgd = _base(initial_balance=900_000.0, monthly_contribution=1_000.0, monthly_expenses=5_500.0, retirement_years=25,
+                 inv1_use_realized_gains_tax_system=True, inv1_realized_gains_tax_rate=0.15,
+                 inv2_use_realized_gains_tax_system=True, inv2_realized_gains_tax_rate=0.15, other_income_streams=streams)
+    g = _check(oracle, cfgd, wm=30)
+    assert 0 < int(g["counters"][0]) < 300  # mixed outcomes: the streams matter
+    with pytest.raises(ValueError):
+        params_from_config(Config(**dict(cfgd, other_income_streams=streams + [_stream(16, True, None, 70.0)])))
+
+
+def test_very_long_horizon(oracle):
+    """100 retirement years after 70 working years: 2040 months per path, T = 171 yearly samples."""
+    cfgd = _base(initial_balance=50_000.0, monthly_contribution=800.0, contribution_growth_rate_annual=0.02,
+                 monthly_expenses=2_500.0, retirement_years=100, current_age=20.0,
+                 inv1_annual_tax_on_gains_rate=0.1, inv2_annual_tax_on_gains_rate=0.1)
+    g = _check(oracle, cfgd, wm=840, n=128)
+    assert g["trajectory"].shape == (171, 128) and g["withdrawal_rate_trajectory"].shape == (100, 128)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_batch_sizes(oracle, n):
+    cfgd = load_golden("paths_injected.json")[8]["cfg"]  # FAILING scenario: mixed outcomes
+    _check(oracle, cfgd, wm=24, n=n, seed=5, begin=2**33 + 11)
+
+
+def test_degenerate_scenarios(oracle):
+    # nothing to simulate before retirement, nothing invested, nothing spent
+    _check(oracle, _base(initial_balance=0.0, monthly_expenses=0.0, retirement_years=1), wm=0, n=70)
+    # all in one asset, 100 % taxes everywhere
+    _check(oracle, _base(allocation_inv1_pct=1.0, inv1_use_realized_gains_tax_system=True, inv1_realized_gains_tax_rate=1.0,
+                         monthly_expenses=3_000.0, retirement_years=12), wm=13, n=200)
+    _check(oracle, _base(allocation_inv1_pct=0.0, inv2_use_realized_gains_tax_system=False, inv2_annual_tax_on_gains_rate=1.0,
+                         inflation_rate_volatility=0.08, monthly_expenses=3_000.0, retirement_years=12), wm=11, n=200)
+    # extreme volatility: growth factors over many orders of magnitude
+    _check(oracle, _base(inv1_returns_volatility=1.5, inv2_premium_over_inflation_volatility=0.8, inflation_rate_volatility=0.3,
+                         monthly_expenses=4_000.0, retirement_years=20), wm=36, n=400)
+
+
+def test_argument_errors():
+    lib = N.load_library()
+    p = params_from_config(Config(**_base()))
+    o = N.McrOutputs()
+    assert lib.mcr_run_batch_host(C.byref(p), 1, 1, 0, 8, -5, None, C.byref(o), 0) == -1 and "working_months" in N.last_error()
+    assert lib.mcr_run_batch_host(C.byref(p), 1, 1, 0, 8, 12, None, C.byref(o), 99) == -1 and "device" in N.last_error()
+    assert lib.mcr_run_batch_host(C.byref(p), 1, 1, 2**64 - 4, 8, 12, None, C.byref(o), 0) == -1  # path range overflows
+    bad = params_from_config(Config(**_base()))
+    bad.n_streams = 17
+    assert lib.mcr_run_batch_host(C.byref(bad), 1, 1, 0, 8, 12, None, C.byref(o), 0) == -1
+    r = N.numpy_rng(5)
+    r.kind = 7
+    assert lib.mcr_run_batch_host_rng(C.byref(p), C.byref(r), 1, 0, 8, 12, None, C.byref(o), 0) == -1
+    with pytest.raises(ValueError):
+        N.numpy_rng(2**300)
+    traj = np.empty((3, 8))
+    o.trajectory = traj.ctypes.data
+    o.path_stride = 4  # < n_paths
+    assert lib.mcr_run_batch_host(C.byref(p), 1, 1, 0, 8, 12, None, C.byref(o), 0) == -1 and "path_stride" in N.last_error()
