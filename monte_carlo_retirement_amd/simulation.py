@@ -334,6 +334,8 @@ class RetirementMonteCarloSimulator:
         """
         n = int(num_simulations)
         wm = int(working_months)
+        if D.is_active():
+            return self._run_sharded(wm, n)
         logger.debug(f"Running {n} simulations on HIP device {self.device} for {wm} working months.")
         batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=self.device)
         batch.launch(self._batch_rng(n), self._stream_id, 0)
@@ -373,6 +375,68 @@ class RetirementMonteCarloSimulator:
             sample_real_trajectories_list,
             wr_observation_counts,
         )
+
+    def _run_sharded(self, wm: int, n: int):
+        """run_monte_carlo_simulations with one process per GPU (torch.distributed initialised): every rank
+        simulates its shard of the global path range [0, n) and keeps its trajectories in its own HBM; the
+        per-path summary is all-gathered (49 B/path), the quantile bands come from the distributed radix
+        select (digit histograms summed across ranks), the sampled paths are contributed by the rank that
+        owns them.  Every rank returns the same 7-tuple, bit-identical to the single-GPU result."""
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        dev = torch.cuda.current_device()
+        begin, count = D.shard_range(n, rank, world)
+        per = -(-n // world)
+        batch = E.DeviceBatch(self._current_params(), wm, max(count, 1), want="full", device=dev)
+        if count > 0:
+            batch.launch(self._batch_rng(n), self._stream_id, begin, count)
+        comm = D._comm_device()
+        # ---- per-path summary: pack [7, per] (six doubles + the flag), all-gather, trim ----
+        fields = list(_FIELD_OF.values())
+        local = torch.zeros((len(fields) + 1, per), dtype=torch.float64, device=batch.success.device)
+        if count > 0:
+            for i, f in enumerate(fields):
+                local[i, :count] = batch.summary[f][:count]
+            local[len(fields), :count] = batch.success[:count].to(torch.float64)
+        local = local.to(comm)
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        parts = [g[:, :D.shard_range(n, r, world)[1]] for r, g in enumerate(gathered)]
+        allf = torch.cat(parts, dim=1).cpu().numpy()
+        cols = {name: allf[i] for i, name in enumerate(_FIELD_OF.keys())}
+        cols["Success"] = allf[len(fields)] != 0.0
+        summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
+        # ---- bands ----
+        traj_q, _ = D.sharded_row_quantiles(batch.trajectory, count, A.TRAJECTORY_QUANTILES)
+        real_q, _ = D.sharded_row_quantiles(batch.real_trajectory, count, A.TRAJECTORY_QUANTILES)
+        wr_q, wr_counts = D.sharded_row_quantiles(batch.withdrawal_rate_trajectory, count, A.WR_QUANTILES)
+        qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
+        trajectory_percentiles_df = pd.DataFrame(traj_q, columns=qcols)
+        real_trajectory_percentiles_df = pd.DataFrame(real_q, columns=qcols)
+        wr_percentiles_df = pd.DataFrame(wr_q, columns=pd.Index(list(A.WR_QUANTILES), dtype="float64"))
+        wr_observation_counts = [int(v) for v in wr_counts.tolist()]
+        # ---- the 5 sampled paths: owner ranks fill their columns, the rest stays 0, sum-reduce ----
+        samples = real_samples = None
+        k = min(n, 5)
+        if k > 0:
+            try:
+                picked = np.random.RandomState(self.main_seed).choice(n, size=k, replace=False)
+                T = batch.sizes.trajectory_len
+                buf = torch.zeros((2, k, T), dtype=torch.float64, device=batch.trajectory.device)
+                for j, g in enumerate(picked):
+                    if begin <= g < begin + count:
+                        buf[0, j] = batch.trajectory[:, g - begin]
+                        buf[1, j] = batch.real_trajectory[:, g - begin]
+                buf = buf.to(comm)
+                D.all_reduce_sum_(buf)
+                samples = buf[0].cpu().numpy().tolist()
+                real_samples = buf[1].cpu().numpy().tolist()
+            except ValueError as ve:
+                logger.error(f"Error sampling trajectories: {ve}")
+        return (summary_df, trajectory_percentiles_df, samples, wr_percentiles_df,
+                real_trajectory_percentiles_df, real_samples, wr_observation_counts)
 
     def _success_probability(self, summary_df: pd.DataFrame) -> float:
         """Share of paths that funded all spending, in percent (simulation.py:1130-1136)."""

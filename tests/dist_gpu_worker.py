@@ -66,6 +66,25 @@ def main():
     res["counts_ok"] = bool(sh["counts"].success == int(whole.counters[0].item()) and sh["counts"].paths == n_paths
                             and sh["counts"].ruin_year_bins.tolist() == whole.ruin_year_bins.cpu().tolist())
     res["success"] = sh["counts"].success
+    # ---- (3) the drop-in class, transparently sharded: search probe + final run
+    from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
+
+    sim = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
+    sim.use_final_seeds()
+    summary, tdf, samples, wdf, rdf, rsamples, wcounts = sim.run_monte_carlo_simulations(wm, n_paths)
+    res["class_summary_equal"] = bool(
+        np.array_equal(summary["Success"].to_numpy(), whole.success.cpu().numpy().astype(bool))
+        and np.array_equal(summary["Final Balance"].to_numpy(), whole.summary["final_balance"].cpu().numpy())
+        and np.array_equal(summary["YearsToRuin"].to_numpy(), whole.summary["years_to_ruin"].cpu().numpy(), equal_nan=True))
+    res["class_bands_equal"] = bool(np.array_equal(tdf.to_numpy(), tq, equal_nan=True) and np.array_equal(rdf.to_numpy(), rq, equal_nan=True)
+                                    and np.array_equal(wdf.to_numpy(), wq, equal_nan=True) and wcounts == wc.tolist())
+    picked = np.random.RandomState(2024).choice(n_paths, size=5, replace=False)
+    res["class_samples_equal"] = bool(np.array_equal(np.array(samples), whole.trajectory[:, :n_paths].cpu().numpy()[:, picked].T)
+                                      and np.array_equal(np.array(rsamples), whole.real_trajectory[:, :n_paths].cpu().numpy()[:, picked].T))
+    sim.use_search_seeds()
+    one = E.DeviceBatch(p, 25, 3000, want="count", device=0)
+    one.launch(2024, 0, 0)
+    res["class_probe_equal"] = sim._probe_success_probability(25, 3000) == float(np.float64(int(one.counters[0].item())) / np.float64(3000) * 100.0)
     with open(f"{out_path}.{rank}", "w") as fh:
         json.dump(res, fh)
     dist.barrier()
