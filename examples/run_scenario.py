@@ -42,6 +42,13 @@ def main() -> int:
     ap.add_argument("--working-months", type=int, default=None, help="skip the search")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # one process per GPU (python -m torch.distributed.run --nproc-per-node N examples/run_scenario.py ...)
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        dist.init_process_group(os.environ.get("MCR_BACKEND", "nccl"))
     raw = load_config_from_json(args.config)
     if args.paths:
         raw["num_simulations_main"] = args.paths
@@ -95,7 +102,13 @@ def main() -> int:
         "seconds": {"search": round(t_search, 3), "final_run": round(t_final, 3)},
     }
     assert len(years) == len(traj_pct) == len(real_pct)
-    print(json.dumps(out))
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

@@ -217,3 +217,40 @@ def test_full_size_invariants_1e6():
     p_gpu = int(c["counters"][0]) / n
     sigma = (p_gpu * (1 - p_gpu) * (1 / n + 1 / n_ref)) ** 0.5
     assert abs(p_gpu - p_ref) < 5 * sigma, (p_gpu, p_ref, sigma)
+
+
+def test_success_probability_within_1e4_of_cpu_at_1e6_paths(oracle):
+    """North-star accuracy clause: success probability within +-1e-4 of the CPU reference at 1e6
+    paths (config.json scenario, identical counters).  The CPU side is the oracle on host threads."""
+    import threading
+
+    g = load_golden("paths_injected.json")[0]
+    p = _params(g["cfg"])
+    n, wm, n_threads = 1_000_000, 233, 32
+    gpu = E.run_batch_host(p, 12345, 1, 0, n, wm, want_trajectories=False)
+    per = n // n_threads
+    parts = [None] * n_threads
+
+    def work(t):
+        begin = t * per
+        cnt = per if t < n_threads - 1 else n - begin
+        parts[t] = oracle.run_batch(p, 12345, 1, begin, cnt, wm, want_trajectories=False)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    cpu_success = np.concatenate([q["success"] for q in parts])
+    cpu_count = int(sum(int(q["counters"][0]) for q in parts))
+    flips = int((gpu["success"] != cpu_success).sum())
+    p_gpu, p_cpu = int(gpu["counters"][0]) / n, cpu_count / n
+    assert abs(p_gpu - p_cpu) <= 1e-4, (p_gpu, p_cpu, flips)
+    assert flips <= 2, flips  # in practice 0: the eps-comparisons sit far from fp64 round-off
+    # per-path terminal wealth: 1e-9 relative to the PATH'S scale (its balance at retirement): a final
+    # balance that is a small remainder of multi-million flows carries the absolute error of those flows
+    cpu_final = np.concatenate([q["final_balance"] for q in parts])
+    scale = np.maximum(np.abs(cpu_final), np.concatenate([q["start_balance"] for q in parts]))
+    err = np.abs(gpu["final_balance"] - cpu_final)
+    assert np.all(err <= ABS + REL * scale), float((err / (ABS + REL * scale)).max())
+    assert float(np.median(err / np.maximum(np.abs(cpu_final), 1.0))) < 1e-12
