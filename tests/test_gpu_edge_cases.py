@@ -102,3 +102,56 @@ def test_argument_errors():
     o.trajectory = traj.ctypes.data
     o.path_stride = 4  # < n_paths
     assert lib.mcr_run_batch_host(C.byref(p), 1, 1, 0, 8, 12, None, C.byref(o), 0) == -1 and "path_stride" in N.last_error()
+
+
+def test_launch_on_a_side_stream_and_reuse_of_buffers():
+    """mcr_run_batch is asynchronous on the hipStream_t it is given: launches on a non-default torch
+    stream, back-to-back into the same buffers, give the same bits as the default stream."""
+    import torch
+
+    cfgd = load_golden("paths_injected.json")[3]["cfg"]
+    p = params_from_config(Config(**cfgd))
+    n, wm = 20_000, 75
+    ref = E.DeviceBatch(p, wm, n, want="full")
+    ref.launch(7, 1, 0)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    b = E.DeviceBatch(p, wm, n, want="full")
+    with torch.cuda.stream(side):
+        b.launch(99, 1, 0)          # first a different seed ...
+        b.zero_counters()
+        b.launch(7, 1, 0)           # ... then overwrite on the same stream, no host sync in between
+    side.synchronize()
+    assert torch.equal(b.trajectory, ref.trajectory) or torch.allclose(b.trajectory, ref.trajectory, rtol=0, atol=0, equal_nan=True)
+    assert torch.equal(b.success, ref.success) and torch.equal(b.counters, ref.counters)
+    assert torch.equal(b.summary["final_balance"], ref.summary["final_balance"])
+
+
+def test_concurrent_calls_from_host_threads(oracle):
+    """The entry points are re-entrant (thread-local error state, per-call device scratch): four host
+    threads simulate different seeds at once, as the reference's server does on executor threads."""
+    import threading
+
+    cfgd = load_golden("paths_injected.json")[8]["cfg"]
+    p = params_from_config(Config(**cfgd))
+    n, wm = 3000, 24
+    expected = [E.run_batch_host(p, 100 + t, t % 2, 0, n, wm) for t in range(4)]
+    got = [None] * 4
+    errs = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = E.run_batch_host(p, 100 + t, t % 2, 0, n, wm)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for t in range(4):
+        for k in ("success", "final_balance", "trajectory", "counters", "ruin_year_bins"):
+            assert np.array_equal(got[t][k], expected[t][k], equal_nan=True), (t, k)
