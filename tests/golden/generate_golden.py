@@ -457,6 +457,21 @@ def gen_numpy_native_batch():
     return out
 
 
+def gen_config_schema():
+    """The reference's pydantic schema (field names, bounds, defaults, aliases, required set) as data."""
+    def strip(o):
+        if isinstance(o, dict):
+            o.pop("description", None)
+            o.pop("title", None)
+            for v in o.values():
+                strip(v)
+        elif isinstance(o, list):
+            for v in o:
+                strip(v)
+        return o
+    return strip(json.loads(json.dumps(RefConfig.model_json_schema())))
+
+
 def frame_to_jsonable(df):
     if df is None:
         return None
@@ -581,6 +596,8 @@ def main():
     def want(k):
         return only is None or k in only
 
+    if want("schema"):
+        dump("config_schema.json", gen_config_schema())
     if want("helpers"):
         dump("helpers.json", gen_helpers())
     if want("deterministic"):

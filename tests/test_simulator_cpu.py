@@ -140,3 +140,23 @@ def test_search_replays_reference_run(idx):
     assert curve == g["search_curve"]
     assert events == g["events"]
     assert sim._stream_name == "search"
+
+
+def test_config_schema_equals_the_references():
+    """Field names, types, bounds, defaults, aliases and the required set are the reference's
+    (tests/golden/config_schema.json = RefConfig.model_json_schema() without prose)."""
+    import json
+
+    def strip(o):
+        if isinstance(o, dict):
+            o.pop("description", None)
+            o.pop("title", None)
+            for v in o.values():
+                strip(v)
+        elif isinstance(o, list):
+            for v in o:
+                strip(v)
+        return o
+
+    mine = strip(json.loads(json.dumps(Config.model_json_schema())))
+    assert mine == load_golden("config_schema.json")
