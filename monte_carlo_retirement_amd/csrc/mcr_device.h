@@ -139,14 +139,23 @@ __device__ __forceinline__ double monthly_gross(double a, double b, double z, co
     return fexp(a + b * z, tab);
 }
 
+// STRICT vs path form of the helpers.  Inside the path kernel the state obeys 0 <= balance,
+// 0 <= cost basis, 0 <= rate <= 1 and "amount sold <= amount held" by construction, which makes several
+// clamps of the reference exact no-ops in IEEE arithmetic (x <= y => fl(y - x) >= 0; f <= 1, c >= 0 =>
+// fl(c f) <= c; fl(x / y) <= 1 for x <= y).  STRICT = true keeps every clamp for arbitrary inputs (the
+// unit-function entry point, bit-exact vs the reference on its test vectors); STRICT = false drops the
+// provable no-ops — identical results on every reachable state, ~3 % fewer VALU instructions.
+
 // _net_liquidation_value (:256-272); rate = realized rate if that system applies else 0.0.
+template <bool STRICT = true>
 __device__ __forceinline__ double net_liquidation_value(double bal, double cb, double rate) {
     const double tax = fmax(0.0, bal - cb) * rate;
-    const double v = fmax(0.0, bal - tax);
+    const double v = STRICT ? fmax(0.0, bal - tax) : bal - tax;  // tax <= bal when cb >= 0, rate <= 1
     return bal <= kEps ? 0.0 : v;
 }
 
 // _calculate_withdrawal_and_update (:201-254), branch-free.
+template <bool STRICT = true>
 __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
                                          double& gross_out, double& net_out) {
     const bool skip = (bal <= kEps) || (net_target <= 0.0);              // :218
@@ -154,13 +163,15 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
     const double gain_fraction = div_by(fmax(0.0, bal - cb), bal, inv_bal);  // :221
     const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
     const double gross = fmin(fdiv(net_target, net_fraction), bal);      // :228-231
-    const double fraction_sold = fmin(1.0, div_by(gross, bal, inv_bal)); // :233
-    const double basis_removed = fmin(cb, cb * fraction_sold);           // :234
+    const double sold = div_by(gross, bal, inv_bal);
+    const double fraction_sold = STRICT ? fmin(1.0, sold) : sold;        // :233  (gross <= bal)
+    const double basis_part = cb * fraction_sold;
+    const double basis_removed = STRICT ? fmin(cb, basis_part) : basis_part;  // :234  (fraction <= 1, cb >= 0)
     const double taxable_gain = fmax(0.0, gross - basis_removed);        // :235
     const double tax_paid = taxable_gain * rate;                         // :236-240
-    const double net_cash = fmax(0.0, gross - tax_paid);                 // :241
-    double nb = fmax(0.0, bal - gross);                                  // :243
-    double ncb = fmax(0.0, cb - basis_removed);                          // :244
+    const double net_cash = STRICT ? fmax(0.0, gross - tax_paid) : gross - tax_paid;  // :241 (tax <= gross)
+    double nb = STRICT ? fmax(0.0, bal - gross) : bal - gross;           // :243
+    double ncb = STRICT ? fmax(0.0, cb - basis_removed) : cb - basis_removed;  // :244
     const bool dust = nb <= kEps;                                        // :245-247
     nb = dust ? 0.0 : nb;
     ncb = dust ? 0.0 : ncb;
@@ -171,6 +182,7 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
 }
 
 // _rebalance_portfolio (:274-359), branch-free: the over-weight asset is the seller.
+template <bool STRICT = true>
 __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, double& c1, double& b2,
                                           double& c2) {
     const double total = b1 + b2;                                  // :288
@@ -192,12 +204,13 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
     const double gross_sale = fmin(bs, fdiv(drift, denom));        // :311
     const double fraction_sold = div_by(gross_sale, bs, inv_bs);   // :312
-    const double basis_removed = fmin(cs, cs * fraction_sold);     // :313
+    const double basis_part = cs * fraction_sold;
+    const double basis_removed = STRICT ? fmin(cs, basis_part) : basis_part;  // :313 (gross_sale <= bs, cs >= 0)
     const double taxable_gain = fmax(0.0, gross_sale - basis_removed);  // :314
     const double tax_paid = taxable_gain * rate_s;                 // :315-319
     const double net_purchase = gross_sale - tax_paid;             // :320
-    double nbs = fmax(0.0, bs - gross_sale);                       // :322
-    double ncs = fmax(0.0, cs - basis_removed);                    // :323
+    double nbs = STRICT ? fmax(0.0, bs - gross_sale) : bs - gross_sale;        // :322
+    double ncs = STRICT ? fmax(0.0, cs - basis_removed) : cs - basis_removed;  // :323
     double nbb = bb + net_purchase;                                // :324
     double ncb = cbuy + net_purchase;                              // :325
     const bool dust_s = nbs <= kEps, dust_b = nbb <= kEps;         // :355-358
@@ -214,6 +227,7 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
 }
 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
+template <bool STRICT = true>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
@@ -221,8 +235,8 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
         const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
         const double total_due = due1 + due2;                         // :390
-        const double cap1 = net_liquidation_value(b1, c1, L.real_rate1);  // :392-397
-        const double cap2 = net_liquidation_value(b2, c2, L.real_rate2);  // :398-403
+        const double cap1 = net_liquidation_value<STRICT>(b1, c1, L.real_rate1);  // :392-397
+        const double cap2 = net_liquidation_value<STRICT>(b2, c2, L.real_rate2);  // :398-403
         const double cap = cap1 + cap2;                               // :404
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
@@ -230,12 +244,12 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
             const double share1 = fdiv(cap1, cap);                    // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
-            withdraw(b1, c1, pay * share1, L.real_rate1, g, net1);    // :411-419
-            withdraw(b2, c2, pay * share2, L.real_rate2, g, net2);    // :420-428
+            withdraw<STRICT>(b1, c1, pay * share1, L.real_rate1, g, net1);    // :411-419
+            withdraw<STRICT>(b2, c2, pay * share2, L.real_rate2, g, net2);    // :420-428
             tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
         }
     }
-    rebalance(L, b1, c1, b2, c2);  // :432-442 (always)
+    rebalance<STRICT>(L, b1, c1, b2, c2);  // :432-442 (always)
     return tax_failed;
 }
 

@@ -133,9 +133,9 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance(L, b1, c1, b2, c2);                                  // :549-553
+        rebalance<false>(L, b1, c1, b2, c2);                           // :549-553
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes<false>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -191,23 +191,23 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     }
                 }
                 if (!stop) {
-                    const double cap1 = net_liquidation_value(b1, c1, L.real_rate1);  // :726-731
-                    const double cap2 = net_liquidation_value(b2, c2, L.real_rate2);  // :732-737
+                    const double cap1 = net_liquidation_value<false>(b1, c1, L.real_rate1);  // :726-731
+                    const double cap2 = net_liquidation_value<false>(b2, c2, L.real_rate2);  // :732-737
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmax(0.0, fmin(need, cap));                 // :739-742
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
                     const double prop1 = cap > kEps ? fdiv(cap1, cap) : P.alloc1;     // :750-754
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
-                    withdraw(b1, c1, target * prop1, L.real_rate1, gw1, nw1);         // :757-765
+                    withdraw<false>(b1, c1, target * prop1, L.real_rate1, gw1, nw1);  // :757-765
                     tg1 += gw1;                                                       // :766
-                    withdraw(b2, c2, target * prop2, L.real_rate2, gw2, nw2);         // :768-776
+                    withdraw<false>(b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg2 += gw2;                                                       // :777
                     if (kSummary) treal += fdiv((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance(L, b1, c1, b2, c2);                                     // :792-796
+                    rebalance<false>(L, b1, c1, b2, c2);                              // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
-                        const bool tf = annual_gain_taxes(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        const bool tf = annual_gain_taxes<false>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
                         yfail = yfail || tf;                                          // :821-822
                     }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            const bool tf = annual_gain_taxes<false>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
             if (tf) { succeeded = false; ytr_bits = f64_bits((double)ry); ruin_bin = ry + 1; }  // :894-896
             put_sample(P.trajectory_len - 1, b1 + b2, infl);                     // :897-898
         }
