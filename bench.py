@@ -86,9 +86,7 @@ def aux_hbm_kernels(torch, n):
     b.launch(12345, 1, 0)
     ms_k1 = timed(lambda: b.launch(12345, 1, 0))
     bytes_k1 = n * (8 * (2 * T + ry + 6) + 1)
-    ms_k3 = timed(lambda: (A.row_quantiles(b.trajectory, n, A.TRAJECTORY_QUANTILES),
-                           A.row_quantiles(b.real_trajectory, n, A.TRAJECTORY_QUANTILES),
-                           A.row_quantiles(b.withdrawal_rate_trajectory, n, A.WR_QUANTILES)))
+    ms_k3 = timed(lambda: A.band_quantiles(b, n))
     bytes_k3 = 4 * 8 * n * (2 * T + ry)  # four streaming digit passes over the slab; passes 4-7 read only candidates
     ms_k2 = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 100))
     bytes_k2 = 2 * 9 * n                 # min/max pass + bin pass, 8 B value + 1 B flag each
@@ -99,7 +97,7 @@ def aux_hbm_kernels(torch, n):
                            "note": "compute-bound: the time-major trajectory stores hide under the fp64 VALU work"},
         "K3_row_quantiles": {"ms": ms_k3, "rows": 2 * T + ry, "algorithmic_read_bytes": bytes_k3,
                              "GBps": bytes_k3 / ms_k3 / 1e6, "frac_of_hbm_peak": bytes_k3 / ms_k3 / 1e6 / HBM_PEAK_GBS,
-                             "note": "includes host-side scratch allocation and result download of three calls"},
+                             "note": "one call over the [2T+ry] slab; includes host-side scratch allocation and result download"},
         "K2_histogram": {"ms": ms_k2, "algorithmic_bytes": bytes_k2, "GBps": bytes_k2 / ms_k2 / 1e6},
     }
 

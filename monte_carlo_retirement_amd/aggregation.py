@@ -20,6 +20,19 @@ TRAJECTORY_QUANTILES = (0.05, 0.10, 0.25, 0.50, 0.75, 0.90, 0.95)
 WR_QUANTILES = (0.05, 0.25, 0.50, 0.75, 0.95)
 
 
+#: columns of TRAJECTORY_QUANTILES that make up WR_QUANTILES
+_WR_COLS = [TRAJECTORY_QUANTILES.index(q) for q in WR_QUANTILES]
+
+
+def band_quantiles(batch, n: int, reduce_counts=None, n_total: Optional[int] = None):
+    """All quantile bands of a full-output ``DeviceBatch`` in ONE radix-select call over its
+    [2T+ry, stride] slab: ``(trajectory_q[T,7], real_trajectory_q[T,7], wr_q[ry,5], wr_counts[ry])``.
+    The WR percentile set is a subset of the trajectory set, so the WR rows simply keep 5 of the 7 columns."""
+    T = batch.sizes.trajectory_len
+    q, counts = row_quantiles(batch.slab, n, TRAJECTORY_QUANTILES, reduce_counts=reduce_counts, n_total=n_total)
+    return q[:T], q[T:2 * T], np.ascontiguousarray(q[2 * T:][:, _WR_COLS]), counts[2 * T:]
+
+
 def _pandas_q(qs: Sequence[float]) -> np.ndarray:
     """pandas hands ``qs * 100`` to np.percentile, which divides by 100 again
     (pandas/core/array_algos/quantile.py, numpy percentile): reproduce that round trip."""

@@ -143,6 +143,19 @@ def sharded_row_quantiles(rows, n_local: int, qs):
     return A.row_quantiles(rows, n_local, qs, reduce_counts=all_reduce_sum_, n_total=int(tot.item()))
 
 
+def sharded_band_quantiles(batch, n_local: int):
+    """``aggregation.band_quantiles`` over rows sharded across the ranks (exact global bands)."""
+    import torch
+
+    from . import aggregation as A
+
+    if not is_active():
+        return A.band_quantiles(batch, n_local)
+    tot = torch.tensor([int(n_local)], dtype=torch.int64, device=_comm_device())
+    all_reduce_sum_(tot)
+    return A.band_quantiles(batch, n_local, reduce_counts=all_reduce_sum_, n_total=int(tot.item()))
+
+
 def run_sharded_bands(params, rng_or_seed, stream_id: int, n_total: int, working_months: int, n_bins: int = 100):
     """BASELINE configs[2]/[3] on N GPUs: every rank simulates its shard of the global path range with
     full trajectory output kept in its own HBM; counters and histogram bins are summed, the histogram
@@ -166,9 +179,7 @@ def run_sharded_bands(params, rng_or_seed, stream_id: int, n_total: int, working
         all_reduce_sum_(vec)
     red = unpack_counts(vec.cpu().numpy(), ry)
     out = {"counts": red, "shard": (begin, count)}
-    out["trajectory_q"], _ = sharded_row_quantiles(batch.trajectory, count, A.TRAJECTORY_QUANTILES)
-    out["real_trajectory_q"], _ = sharded_row_quantiles(batch.real_trajectory, count, A.TRAJECTORY_QUANTILES)
-    out["wr_q"], out["wr_counts"] = sharded_row_quantiles(batch.withdrawal_rate_trajectory, count, A.WR_QUANTILES)
+    out["trajectory_q"], out["real_trajectory_q"], out["wr_q"], out["wr_counts"] = sharded_band_quantiles(batch, count)
     fb, ok = batch.summary["final_balance"][:max(count, 0)], batch.success[:max(count, 0)]
     out["hist_bins"], out["hist_edges"] = A.success_histogram(
         fb, ok, n_bins,

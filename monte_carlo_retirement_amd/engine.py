@@ -191,11 +191,15 @@ class DeviceBatch:
             for k in SUMMARY_FIELDS:
                 self.summary[k] = torch.empty(self.n_paths, dtype=f64, device=dev)
             self.success = torch.empty(self.n_paths, dtype=torch.uint8, device=dev)
+        self.slab = None
         if want == "full":
+            # one [2T+ry, stride] slab (nominal | real | withdrawal-rate rows) so the quantile bands of all
+            # rows come from a single radix-select call
             T, ry = self.sizes.trajectory_len, self.sizes.retirement_years
-            self.trajectory = torch.empty((T, self.stride), dtype=f64, device=dev)
-            self.real_trajectory = torch.empty((T, self.stride), dtype=f64, device=dev)
-            self.withdrawal_rate_trajectory = torch.empty((ry, self.stride), dtype=f64, device=dev)
+            self.slab = torch.empty((2 * T + ry, self.stride), dtype=f64, device=dev)
+            self.trajectory = self.slab[:T]
+            self.real_trajectory = self.slab[T:2 * T]
+            self.withdrawal_rate_trajectory = self.slab[2 * T:]
         o = McrOutputs()
         o.path_stride = self.stride
         o.counters = self.counters.data_ptr()

@@ -344,9 +344,7 @@ class RetirementMonteCarloSimulator:
         cols["Success"] = batch.success.cpu().numpy().astype(bool)
         summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
 
-        traj_q, _ = A.row_quantiles(batch.trajectory, n, A.TRAJECTORY_QUANTILES)
-        real_q, _ = A.row_quantiles(batch.real_trajectory, n, A.TRAJECTORY_QUANTILES)
-        wr_q, wr_counts = A.row_quantiles(batch.withdrawal_rate_trajectory, n, A.WR_QUANTILES)
+        traj_q, real_q, wr_q, wr_counts = A.band_quantiles(batch, n)
         qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
         trajectory_percentiles_df = pd.DataFrame(traj_q, columns=qcols)
         real_trajectory_percentiles_df = pd.DataFrame(real_q, columns=qcols)
@@ -409,9 +407,7 @@ class RetirementMonteCarloSimulator:
         cols["Success"] = allf[len(fields)] != 0.0
         summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
         # ---- bands ----
-        traj_q, _ = D.sharded_row_quantiles(batch.trajectory, count, A.TRAJECTORY_QUANTILES)
-        real_q, _ = D.sharded_row_quantiles(batch.real_trajectory, count, A.TRAJECTORY_QUANTILES)
-        wr_q, wr_counts = D.sharded_row_quantiles(batch.withdrawal_rate_trajectory, count, A.WR_QUANTILES)
+        traj_q, real_q, wr_q, wr_counts = D.sharded_band_quantiles(batch, count)
         qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
         trajectory_percentiles_df = pd.DataFrame(traj_q, columns=qcols)
         real_trajectory_percentiles_df = pd.DataFrame(real_q, columns=qcols)

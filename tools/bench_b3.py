@@ -54,9 +54,8 @@ def main():
     k1()
     ms_k1, _ = timed(k1)
     bytes_k1 = n * (8 * (2 * T + ry + 6) + 1)
-    ms_q, (tq, _) = timed(lambda: A.row_quantiles(b.trajectory, n, A.TRAJECTORY_QUANTILES))
-    ms_qr, _ = timed(lambda: A.row_quantiles(b.real_trajectory, n, A.TRAJECTORY_QUANTILES))
-    ms_qw, (wq, wc) = timed(lambda: A.row_quantiles(b.withdrawal_rate_trajectory, n, A.WR_QUANTILES))
+    ms_q, (tq, _rq, wq, wc) = timed(lambda: A.band_quantiles(b, n))
+    ms_qr = ms_qw = 0.0
     bytes_q_pass = 8 * n  # per row per pass
     ms_h, (bins, edges) = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 100))
     ms_h60, _ = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 60))
