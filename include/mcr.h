@@ -210,6 +210,12 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
 #define MCR_HELPER_REBALANCE 2     /* _rebalance_portfolio :274-359;             in[4]=(b1,cb1,b2,cb2) out[4] */
 #define MCR_HELPER_ANNUAL_TAX 3    /* _apply_annual_gain_taxes :361-450;         in[6]=(b1,cb1,b2,cb2,g1,g2) out[5]=(b1,cb1,b2,cb2,tax_failed) */
 #define MCR_HELPER_MONTHLY_GROSS 4 /* _monthly_gross_from_shock :468-474;        in[3]=(mu_log,sigma_log,z) out[1] */
+/* the kernel's specialised fp64 math (csrc/mcr_math.h), exposed so its accuracy can be measured */
+#define MCR_HELPER_MATH_EXP 5      /* in[1]=(x)            out[1]=exp(x)                              */
+#define MCR_HELPER_MATH_DIV 6      /* in[2]=(a,b)          out[1]=a/b (Newton sequence, no scaling)   */
+#define MCR_HELPER_MATH_SQRT 7     /* in[1]=(w)            out[1]=sqrt(w)                             */
+#define MCR_HELPER_MATH_NEG2LOG 8  /* in[1]=(x as uint32)  out[1]=-2 ln((x+0.5) 2^-32)                */
+#define MCR_HELPER_MATH_SINCOS 9   /* in[1]=(x as uint32)  out[2]=(sin, cos)(2 pi (x+0.5) 2^-32)      */
 /* Evaluates helper `which` ON THE DEVICE for n rows (host buffers, row-major). */
 int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out,
                          int64_t n, int device);

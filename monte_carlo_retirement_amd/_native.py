@@ -28,12 +28,22 @@ MCR_HELPER_NLV = 1
 MCR_HELPER_REBALANCE = 2
 MCR_HELPER_ANNUAL_TAX = 3
 MCR_HELPER_MONTHLY_GROSS = 4
+MCR_HELPER_MATH_EXP = 5
+MCR_HELPER_MATH_DIV = 6
+MCR_HELPER_MATH_SQRT = 7
+MCR_HELPER_MATH_NEG2LOG = 8
+MCR_HELPER_MATH_SINCOS = 9
 _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_WITHDRAW: (5, 4),
     MCR_HELPER_NLV: (4, 1),
     MCR_HELPER_REBALANCE: (4, 4),
     MCR_HELPER_ANNUAL_TAX: (6, 5),
     MCR_HELPER_MONTHLY_GROSS: (3, 1),
+    MCR_HELPER_MATH_EXP: (1, 1),
+    MCR_HELPER_MATH_DIV: (2, 1),
+    MCR_HELPER_MATH_SQRT: (1, 1),
+    MCR_HELPER_MATH_NEG2LOG: (1, 1),
+    MCR_HELPER_MATH_SINCOS: (1, 2),
 }
 
 

@@ -338,6 +338,16 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
             out[i] = monthly_gross(x[0] / (double)kMPY, x[1] / sqrt((double)kMPY), x[2], tab);  // :473
             break;
         }
+        case MCR_HELPER_MATH_EXP: out[i] = fexp(in[i], tab); break;
+        case MCR_HELPER_MATH_DIV: out[i] = fdiv(in[2 * i], in[2 * i + 1]); break;
+        case MCR_HELPER_MATH_SQRT: out[i] = fsqrt(in[i]); break;
+        case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab); break;
+        case MCR_HELPER_MATH_SINCOS: {
+            double sn, cs;
+            sincos_u32<true>((uint32_t)in[i], tab, sn, cs);
+            out[2 * i] = sn; out[2 * i + 1] = cs;
+            break;
+        }
         default: break;
     }
 }
@@ -755,6 +765,11 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
         case MCR_HELPER_REBALANCE: n_in = 4; n_out = 4; break;
         case MCR_HELPER_ANNUAL_TAX: n_in = 6; n_out = 5; break;
         case MCR_HELPER_MONTHLY_GROSS: n_in = 3; n_out = 1; break;
+        case MCR_HELPER_MATH_EXP: n_in = 1; n_out = 1; break;
+        case MCR_HELPER_MATH_DIV: n_in = 2; n_out = 1; break;
+        case MCR_HELPER_MATH_SQRT: n_in = 1; n_out = 1; break;
+        case MCR_HELPER_MATH_NEG2LOG: n_in = 1; n_out = 1; break;
+        case MCR_HELPER_MATH_SINCOS: n_in = 1; n_out = 2; break;
         default: set_error("unknown helper %d", which); return MCR_ERR_INVALID_ARG;
     }
     if (!in || !out || n < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }

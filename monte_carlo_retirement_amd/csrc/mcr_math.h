@@ -10,10 +10,11 @@
 //                     the Newton reciprocal is shared by quotients with the same divisor.
 //   fexp              exp(x), |x| < 700: 2^(k/64) table (LDS) + degree-6 polynomial, <= ~1.5 ulp.
 //   neg2_log_u32      -2 ln((x+0.5) 2^-32) straight from the Philox integer: 128-entry table of
-//                     (1/c, -2 ln c) + degree-6 series, absolute error ~1e-17 (Box-Muller radius^2).
-//   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 2 corrections.
+//                     (1/c, -2 ln c) + degree-6 series, <= 1.5 ulp of the result (Box-Muller radius^2).
+//   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 2 corrections, <= 1 ulp.
 //   sincos_u32        sin/cos(2 pi (x+0.5) 2^-32): top 8 bits index a 256-entry (sin,cos) table of
-//                     bin centres, the low 24 bits give |delta| <= pi/256, rotated with short series.
+//                     bin centres, the low 24 bits give |delta| <= pi/256, rotated with short series;
+//                     absolute error < 3e-16.  (All bounds measured on the device: tests/test_gpu_math.py.)
 // Tables are correctly rounded (tools/gen_tables.py) and staged in LDS once per workgroup.
 #pragma once
 

@@ -1,0 +1,69 @@
+"""Accuracy of the kernel's domain-specialised fp64 math (csrc/mcr_math.h), measured on the device
+against long-double / exact references.  These are the claims the path tolerance rests on."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from monte_carlo_retirement_amd import _native as N
+from monte_carlo_retirement_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulps(got, exact_ld):
+    got = np.asarray(got, dtype=np.float64)
+    ref = exact_ld.astype(np.float64)
+    ulp = np.spacing(np.abs(ref))
+    return np.abs((got.astype(np.longdouble) - exact_ld) / ulp.astype(np.longdouble)).astype(np.float64)
+
+
+def test_division_is_correctly_rounded_in_the_balance_range():
+    """fdiv == IEEE a/b bit-for-bit for operands anywhere in the path's dynamic range."""
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-1, 1, 400_000) * 10.0 ** rng.uniform(-8, 16, 400_000)
+    b = rng.uniform(0.1, 1, 400_000) * 10.0 ** rng.uniform(-7, 16, 400_000) * rng.choice([-1.0, 1.0], 400_000)
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_DIV, None, np.column_stack((a, b)))[:, 0]
+    assert np.array_equal(got, a / b)
+
+
+def test_exp_within_1_5_ulp():
+    x = np.concatenate([np.random.default_rng(2).uniform(-3, 3, 300_000), np.linspace(-20, 20, 50_001), [0.0, -0.0, 1e-300]])
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_EXP, None, x.reshape(-1, 1))[:, 0]
+    u = _ulps(got, np.exp(x.astype(np.longdouble)))
+    assert u.max() <= 1.5, u.max()
+    assert np.mean(u <= 0.5) > 0.70   # mostly correctly rounded (measured: 76 %)
+
+
+def test_sqrt_within_1_ulp():
+    w = np.concatenate([np.random.default_rng(3).uniform(0, 46, 300_000), 10.0 ** np.random.default_rng(4).uniform(-10, 2, 100_000)])
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_SQRT, None, w.reshape(-1, 1))[:, 0]
+    u = _ulps(got, np.sqrt(w.astype(np.longdouble)))
+    assert u.max() <= 1.0, u.max()
+
+
+def test_neg2log_absolute_error():
+    """-2 ln u of the Box-Muller radius: what matters is the ABSOLUTE error (the radius^2 feeds sigma*z)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.integers(0, 2**32, 400_000), [0, 1, 2, 2**31, 2**32 - 1, 2**32 - 2]]).astype(np.float64)
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_NEG2LOG, None, x.reshape(-1, 1))[:, 0]
+    u = (x.astype(np.longdouble) + np.longdouble(0.5)) * np.longdouble(2.0) ** -32
+    exact = -2 * np.log(u)
+    err = np.abs(got.astype(np.longdouble) - exact).astype(np.float64)
+    bound = np.maximum(1.5 * np.spacing(got), 1.5e-16)  # <= 1.5 ulp of the result (measured 1.35), 1.5e-16 near u -> 1
+    assert np.all(err <= bound), float((err / bound).max())
+    assert np.all(got > 0)
+
+
+def test_sincos_absolute_error():
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.integers(0, 2**32, 400_000), [0, 2**24 - 1, 2**24, 2**31 - 1, 2**31, 2**32 - 1]]).astype(np.float64)
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_SINCOS, None, x.reshape(-1, 1))
+    # long-double pi is only ~1e-19 accurate: fine against a 3e-16 bound
+    two_pi = np.longdouble("6.283185307179586476925286766559005768")
+    ang = (x.astype(np.longdouble) + np.longdouble(0.5)) * two_pi / np.longdouble(2.0) ** 32
+    es = np.abs(got[:, 0].astype(np.longdouble) - np.sin(ang)).astype(np.float64)
+    ec = np.abs(got[:, 1].astype(np.longdouble) - np.cos(ang)).astype(np.float64)
+    assert max(es.max(), ec.max()) < 3e-16, (es.max(), ec.max())
+    assert np.abs(got[:, 0] ** 2 + got[:, 1] ** 2 - 1.0).max() < 5e-16
