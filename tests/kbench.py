@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel iteration tool (GPU box): time the path kernel and check it against the oracle.
 
-    python tools/kbench.py [--paths 1000000] [--reps 5] [--check 20000]
+    python tests/kbench.py [--paths 1000000] [--reps 5] [--check 20000]
 Prints ms/launch for the count-only and full-output variants on the config.json (C1) and
 jorge.json (C3) workloads, the success counts, and the parity of a `--check`-path batch vs the
 CPU oracle (flipped flags, max relative error of the summary fields)."""
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))  # tests/ -> repo root
 sys.path.insert(0, REPO)
 
 
