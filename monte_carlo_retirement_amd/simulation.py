@@ -122,6 +122,23 @@ def trajectory_time_points(working_months: int, retirement_years: int) -> List[f
     return pts
 
 
+def _summary_frame(batch, n: int) -> pd.DataFrame:
+    """summary_df (simulation.py:1012-1027) from a device batch: ONE packed device->host transfer of the
+    six float columns through a pinned buffer (the per-path frame is the only O(n) object that has to cross
+    PCIe), then a no-copy DataFrame with the reference's column order and dtypes."""
+    torch = batch.torch
+    fields = list(_FIELD_OF.items())
+    packed = torch.stack([batch.summary[f][:n] for _, f in fields])            # [6, n] on the device
+    host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+    host.copy_(packed, non_blocking=False)
+    flags = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    flags.copy_(batch.success[:n])
+    h = host.numpy()
+    cols = {name: h[i] for i, (name, _) in enumerate(fields)}
+    cols["Success"] = flags.numpy().view(np.bool_)
+    return pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS}, copy=False)
+
+
 def _fold_seed_u64(seed: int) -> int:
     """Philox key = the seed folded to 64 bits (seeds are unbounded Python ints in the Config)."""
     s, out = int(seed), 0
@@ -340,9 +357,7 @@ class RetirementMonteCarloSimulator:
         batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=self.device)
         batch.launch(self._batch_rng(n), self._stream_id, 0)
 
-        cols = {name: batch.summary[field].cpu().numpy() for name, field in _FIELD_OF.items()}
-        cols["Success"] = batch.success.cpu().numpy().astype(bool)
-        summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
+        summary_df = _summary_frame(batch, n)
 
         traj_q, real_q, wr_q, wr_counts = A.band_quantiles(batch, n)
         qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
