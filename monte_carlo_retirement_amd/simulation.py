@@ -122,6 +122,14 @@ def trajectory_time_points(working_months: int, retirement_years: int) -> List[f
     return pts
 
 
+def _gather_columns(rows, picked) -> np.ndarray:
+    """``rows[:, picked].T`` as a host array, one strided column view per pick (host-side 64-bit pointer
+    arithmetic; a bad index raises IndexError here, whereas torch.index_select would assert on the device)."""
+    import torch
+
+    return torch.stack([rows[:, int(g)] for g in picked]).cpu().numpy()
+
+
 def _summary_frame(batch, n: int) -> pd.DataFrame:
     """summary_df (simulation.py:1012-1027) from a device batch: ONE packed device->host transfer of the
     six float columns through a pinned buffer (the per-path frame is the only O(n) object that has to cross
@@ -374,9 +382,8 @@ class RetirementMonteCarloSimulator:
         if k > 0:
             try:
                 picked = np.random.RandomState(self.main_seed).choice(n, size=k, replace=False)
-                idx = batch.torch.as_tensor(picked, device=batch.trajectory.device, dtype=batch.torch.long)
-                sample_trajectories_list = batch.trajectory.index_select(1, idx).T.cpu().numpy().tolist()
-                sample_real_trajectories_list = batch.real_trajectory.index_select(1, idx).T.cpu().numpy().tolist()
+                sample_trajectories_list = _gather_columns(batch.trajectory, picked).tolist()
+                sample_real_trajectories_list = _gather_columns(batch.real_trajectory, picked).tolist()
             except ValueError as ve:  # e.g. main_seed >= 2**32: the reference logs and returns None (:1079-1083)
                 logger.error(f"Error sampling trajectories: {ve}")
         return (

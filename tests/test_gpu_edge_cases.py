@@ -155,3 +155,42 @@ def test_concurrent_calls_from_host_threads(oracle):
     for t in range(4):
         for k in ("success", "final_balance", "trajectory", "counters", "ruin_year_bins"):
             assert np.array_equal(got[t][k], expected[t][k], equal_nan=True), (t, k)
+
+
+def test_very_large_batches_use_64bit_addressing(oracle):
+    """2e8 paths in one count-only launch, and a 3.3e7-path full-output batch whose [2T+ry, stride] slab
+    has > 2^32 elements (36 GB): counters add up, and paths spot-checked across the whole range (incl. the
+    last one) equal the oracle's."""
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    cfgd = load_golden("paths_injected.json")[4]["cfg"]   # jorge.json, rho = 0.3
+    p = params_from_config(Config(**cfgd))
+    wm = 75
+    big = E.DeviceBatch(p, wm, 200_000_000, want="count")
+    big.launch(31337, 1, 0)
+    c = big.counters.cpu().tolist()
+    assert c[1] == 200_000_000 and 0.985 < c[0] / c[1] < 0.997
+    assert int(big.ruin_year_bins.sum().item()) == c[1] - c[0]
+    del big
+
+    n = 33_000_000
+    b = E.DeviceBatch(p, wm, n, want="full")
+    assert b.slab.numel() > 2**32
+    b.launch(31337, 1, 0)
+    picks = [0, 1, 63, 64, 2**24 + 5, 29_999_999, n // 2, n - 2, n - 1]
+    traj = torch.stack([b.trajectory[:, g] for g in picks], dim=1).cpu().numpy()
+    wr = torch.stack([b.withdrawal_rate_trajectory[:, g] for g in picks], dim=1).cpu().numpy()
+    fin = torch.stack([b.summary["final_balance"][g] for g in picks]).cpu().numpy()
+    for j, g in enumerate(picks):
+        o = oracle.run_batch(p, 31337, 1, g, 1, wm)
+        np.testing.assert_allclose(traj[:, j], o["trajectory"][:, 0], rtol=REL, atol=ABS)
+        np.testing.assert_allclose(wr[:, j], o["withdrawal_rate_trajectory"][:, 0], rtol=REL, equal_nan=True)
+        np.testing.assert_allclose(fin[j], o["final_balance"][0], rtol=REL, atol=ABS)
+    assert int(b.counters[1].item()) == n
+    # bands over the > 2^32-element slab: medians must be monotone sane and the counts complete
+    tq, rq, wq, wc = A.band_quantiles(b, n)
+    assert tq.shape == (b.sizes.trajectory_len, 7) and np.all(np.diff(tq, axis=1) >= 0)
+    assert wc[0] == n and np.all(np.diff(wc) <= 0)
+    assert tq[0].tolist() == [cfgd["initial_balance"]] * 7
