@@ -1,11 +1,14 @@
 // mcr_hip.hip — kernels + C ABI (include/mcr.h) of the MI355X Monte Carlo retirement engine.
 //
-// K1  path_kernel<MODE>   one path per lane; the whole horizon in registers
+// K1  path_kernel<MODE, RNG>   one path per lane; the whole horizon in registers
 //       MODE 0: success count only          (no per-path HBM traffic; BASELINE config 2)
 //       MODE 1: + per-path summary fields   (SoA, 49 B/path)
 //       MODE 2: + yearly trajectories       (time-major [T][N]: 512 contiguous bytes per wave store)
+//       RNG 0: Philox4x32-10 + Box-Muller (mcr_device.h);  RNG 1: NumPy's SeedSequence -> PCG64 ->
+//              ziggurat stream (mcr_numpy_rng.h), for literal seed parity with the reference
 //     reductions: wave ballot+popcount -> LDS -> one global atomic per workgroup.
-// Helpers: helper_kernel (device unit functions), shocks_kernel (_draw_shock_path).
+// Helpers: helper_kernel (device unit functions + the specialised math of mcr_math.h),
+//          shocks_kernel / np_shocks_kernel (_draw_shock_path).
 // Aggregation kernels (quantiles / histogram) live in mcr_aggregate.hip.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/build.py).  gfx950 only.

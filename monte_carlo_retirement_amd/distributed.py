@@ -6,8 +6,11 @@ cut into contiguous shards, one per rank; the Philox counter carries the GLOBAL 
 the union of the shards is bit-identical to a single-GPU run.  The only exchange step is a
 sum all-reduce of one small int64 vector ``[success, paths, wr_obs_counts[ry], ruin_bins[ry+2]]``
 (RCCL over xGMI when the backend is "nccl"; latency-bound, < 2 KB) — plus, for the histogram of
-final balances, a min/max all-reduce of two doubles before the bins are summed.
-Trajectories never leave the GPU that produced them.
+final balances, a min/max all-reduce of two doubles before the bins are summed, and for exact
+cross-GPU quantile bands the radix select's digit histograms summed once per pass
+(``sharded_row_quantiles``).  Trajectories never leave the GPU that produced them; the only O(n)
+exchange is the all-gather of the 49 B/path summary when a caller wants the per-path frame
+(``RetirementMonteCarloSimulator.run_monte_carlo_simulations`` under a process group).
 
 ``torch.distributed`` is plumbing only; all path arithmetic is in the HIP kernels.
 """
