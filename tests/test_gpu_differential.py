@@ -1,0 +1,93 @@
+"""Randomised differential test: the HIP path engine vs the CPU oracle (itself pinned bit-exactly to the
+reference) over a few hundred random scenarios — zero/one allocations, 0 %/100 % taxes on either system,
+huge volatilities, negative means, up to 6 random income streams, random horizons and streams."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from monte_carlo_retirement_amd import Config, params_from_config
+from monte_carlo_retirement_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+REL, ABS = 1e-9, 1e-6
+
+
+def _random_config(rng):
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]  # noqa: E731
+    age = float(pick(25.0, 40.5, 58.25, 66.0))
+    streams = []
+    for s in range(int(rng.integers(0, 7))):
+        streams.append({
+            "name": f"s{s}", "monthly_amount_today": float(pick(0.0, rng.uniform(50, 6000))),
+            "start_at_age": float(age + rng.uniform(-3, 25)), "duration_years": pick(None, int(rng.integers(0, 12))),
+            "inflation_indexed": bool(rng.integers(2)), "tax_rate": float(pick(0.0, 1.0, rng.uniform(0, 0.6))),
+        })
+    return dict(
+        scenario="fuzz", initial_balance=float(pick(0.0, rng.uniform(1e3, 5e4), rng.uniform(1e5, 3e6))),
+        monthly_contribution=float(pick(0.0, rng.uniform(0, 9000))),
+        contribution_growth_rate_annual=float(pick(0.0, rng.uniform(0, 0.12))),
+        monthly_expenses=float(pick(0.0, rng.uniform(300, 12000))), current_age=age,
+        retirement_years=int(rng.integers(1, 41)),
+        allocation_inv1_pct=float(pick(0.0, 1.0, rng.uniform(0, 1))),
+        inv1_returns_mean=float(rng.uniform(-0.4, 0.6)), inv1_returns_volatility=float(pick(0.0, rng.uniform(0, 0.9))),
+        inv1_annual_tax_on_gains_rate=float(pick(0.0, 1.0, rng.uniform(0, 1))),
+        inv1_realized_gains_tax_rate=float(pick(0.0, 1.0, rng.uniform(0, 1))),
+        inv1_use_realized_gains_tax_system=bool(rng.integers(2)),
+        inv2_premium_over_inflation_mean=float(rng.uniform(-0.3, 0.4)),
+        inv2_premium_over_inflation_volatility=float(pick(0.0, rng.uniform(0, 0.5))),
+        inv2_annual_tax_on_gains_rate=float(pick(0.0, 1.0, rng.uniform(0, 1))),
+        inv2_realized_gains_tax_rate=float(pick(0.0, 1.0, rng.uniform(0, 1))),
+        inv2_use_realized_gains_tax_system=bool(rng.integers(2)),
+        inflation_rate_mean=float(rng.uniform(-0.08, 0.3)), inflation_rate_volatility=float(pick(0.0, rng.uniform(0, 0.15))),
+        equity_inflation_correlation=float(pick(0.0, -1.0, 1.0, rng.uniform(-1, 1))),
+        num_simulations_main=1, num_simulations_search=1, target_probability=50.0, starting_working_months_search=0,
+        seed=None, num_processes=1, other_income_streams=streams,
+    )
+
+
+def test_randomised_scenarios_match_the_oracle(oracle):
+    rng = np.random.default_rng(20260101)
+    n = 256
+    stats = {"paths": 0, "failed": 0, "pre_retirement": 0, "terminal": 0, "scenarios": 0}
+    for k in range(240):
+        cfgd = _random_config(rng)
+        wm = int(rng.choice([0, 1, 11, 12, 13, 25, int(rng.integers(0, 200))]))
+        if k % 10 == 9:  # a family prone to PRE-RETIREMENT annual-tax failure (simulation.py:572-573, :627-634):
+            # inv1 booms and is taxed annually at 100 %, its gains are swept into inv2, which crashes
+            cfgd.update(allocation_inv1_pct=0.5, inv1_returns_mean=1.5, inv1_returns_volatility=0.5,
+                        inv1_use_realized_gains_tax_system=False, inv1_annual_tax_on_gains_rate=1.0,
+                        inv2_premium_over_inflation_mean=-0.9, inv2_premium_over_inflation_volatility=0.3,
+                        inv2_use_realized_gains_tax_system=True, inv2_realized_gains_tax_rate=0.5,
+                        inflation_rate_mean=0.0, inflation_rate_volatility=0.0, initial_balance=100_000.0)
+            wm = int(rng.choice([12, 14, 25, 37]))
+        seed = int(rng.integers(0, 2**63))
+        stream = int(rng.integers(2))
+        begin = int(rng.choice([0, 2**32 - 100, 2**40]))
+        p = params_from_config(Config(**cfgd))
+        g = E.run_batch_host(p, seed, stream, begin, n, wm)
+        c = oracle.run_batch(p, seed, stream, begin, n, wm)
+        ctx = f"scenario {k}: wm={wm} cfg={cfgd}"
+        assert np.array_equal(g["success"], c["success"]), ctx
+        assert g["counters"].tolist() == c["counters"].tolist(), ctx
+        assert g["ruin_year_bins"].tolist() == c["ruin_year_bins"].tolist(), ctx
+        assert g["wr_obs_counts"].tolist() == c["wr_obs_counts"].tolist(), ctx
+        scale = np.maximum(1.0, np.abs(c["trajectory"]).max(axis=0))   # the path's own money scale
+        for key in ("trajectory", "real_trajectory"):
+            err = np.abs(g[key] - c[key])
+            assert np.all(err <= ABS + REL * np.maximum(np.abs(c[key]), scale)), (ctx, key, float(err.max()))
+        assert np.array_equal(np.isnan(g["withdrawal_rate_trajectory"]), np.isnan(c["withdrawal_rate_trajectory"])), ctx
+        np.testing.assert_allclose(g["withdrawal_rate_trajectory"], c["withdrawal_rate_trajectory"], rtol=1e-8, atol=1e-9, equal_nan=True, err_msg=ctx)
+        np.testing.assert_allclose(g["years_to_ruin"], c["years_to_ruin"], rtol=0, atol=0, equal_nan=True, err_msg=ctx)
+        for key in ("start_balance", "final_balance", "first_year_gross_withdrawal", "first_year_real_gross_withdrawal", "inflation_at_retirement"):
+            err = np.abs(g[key] - c[key])
+            assert np.all(err <= ABS + REL * np.maximum(np.abs(c[key]), scale)), (ctx, key, float(err.max()))
+        stats["paths"] += n
+        stats["scenarios"] += 1
+        stats["failed"] += int(n - c["counters"][0])
+        stats["pre_retirement"] += int(c["ruin_year_bins"][0])
+        stats["terminal"] += int(c["ruin_year_bins"][-1])
+    # the sweep must actually reach the rare branches
+    assert stats["failed"] > 5000 and stats["failed"] < stats["paths"] - 5000, stats
+    assert stats["pre_retirement"] > 0, stats
