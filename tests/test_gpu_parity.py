@@ -226,7 +226,7 @@ def test_success_probability_within_1e4_of_cpu_at_1e6_paths(oracle):
 
     g = load_golden("paths_injected.json")[0]
     p = _params(g["cfg"])
-    n, wm, n_threads = 1_000_000, 233, 32
+    n, wm, n_threads = 1_000_000, 233, 16
     gpu = E.run_batch_host(p, 12345, 1, 0, n, wm, want_trajectories=False)
     per = n // n_threads
     parts = [None] * n_threads
