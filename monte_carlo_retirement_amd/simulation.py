@@ -185,6 +185,10 @@ class RetirementMonteCarloSimulator:
         self._stream_name = "final"
         self._engine_seed = _fold_seed_u64(self.main_seed)
         self.device = int(device)
+        #: under torch.distributed, batches smaller than this are computed in full on EVERY rank (identical
+        #: results, no communication): a 50 000-path probe is latency-bound (~1 ms) and sharding it would add
+        #: an all-reduce + host sync per probe.  Larger batches are sharded across the ranks.
+        self.shard_min_paths = 1_000_000
         # NumPy stream bookkeeping: children spawned so far per stream, and the offset at which each
         # (stream, n) batch was spawned — the reference's _path_seed_cache rule (:154, :192-199)
         self._np_children_spawned = {"search": 0, "final": 0}
@@ -229,6 +233,15 @@ class RetirementMonteCarloSimulator:
             int(np.random.SeedSequence(self.main_seed, spawn_key=(self._stream_id, off + j)).generate_state(1)[0])
             for j in range(n)
         ]
+
+    def _local_device(self) -> int:
+        """The GPU this process computes on: the configured device, or — with one process per GPU under
+        torch.distributed — the rank's current device."""
+        if D.is_active():
+            import torch
+
+            return int(torch.cuda.current_device())
+        return self.device
 
     def _np_offset(self, n: int) -> int:
         """Spawn offset of the (active stream, n) batch: assigned on first use, then cached."""
@@ -359,10 +372,11 @@ class RetirementMonteCarloSimulator:
         """
         n = int(num_simulations)
         wm = int(working_months)
-        if D.is_active():
+        if D.is_active() and n >= self.shard_min_paths:
             return self._run_sharded(wm, n)
-        logger.debug(f"Running {n} simulations on HIP device {self.device} for {wm} working months.")
-        batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=self.device)
+        dev = self._local_device()
+        logger.debug(f"Running {n} simulations on HIP device {dev} for {wm} working months.")
+        batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=dev)
         batch.launch(self._batch_rng(n), self._stream_id, 0)
 
         summary_df = _summary_frame(batch, n)
@@ -469,7 +483,7 @@ class RetirementMonteCarloSimulator:
         """Success % of a batch from the count-only kernel (no per-path HBM traffic).  Equals
         ``_success_probability(run_monte_carlo_simulations(...)[0])`` bit-for-bit: count/n*100."""
         n = int(num_simulations)
-        if D.is_active():
+        if D.is_active() and n >= self.shard_min_paths:
             # one process per GPU: each rank simulates its shard of [0, n), counts are summed with a
             # single all-reduce, every rank sees the same probability (and replays the same search)
             params = self._current_params()
@@ -478,7 +492,7 @@ class RetirementMonteCarloSimulator:
                 D.gpu_count_runner(params, self._batch_rng(n), self._stream_id, int(working_months)),
             )
             return red.success_probability_pct
-        batch = E.DeviceBatch(self._current_params(), int(working_months), n, want="count", device=self.device)
+        batch = E.DeviceBatch(self._current_params(), int(working_months), n, want="count", device=self._local_device())
         batch.launch(self._batch_rng(n), self._stream_id, 0)
         ok = int(batch.counters[N.MCR_CTR_SUCCESS].item())
         return float(np.float64(ok) / np.float64(n) * 100.0)

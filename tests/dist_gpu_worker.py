@@ -70,6 +70,7 @@ def main():
     from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
 
     sim = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
+    sim.shard_min_paths = 0  # force sharding even for this small batch
     sim.use_final_seeds()
     summary, tdf, samples, wdf, rdf, rsamples, wcounts = sim.run_monte_carlo_simulations(wm, n_paths)
     res["class_summary_equal"] = bool(
@@ -84,7 +85,17 @@ def main():
     sim.use_search_seeds()
     one = E.DeviceBatch(p, 25, 3000, want="count", device=0)
     one.launch(2024, 0, 0)
-    res["class_probe_equal"] = sim._probe_success_probability(25, 3000) == float(np.float64(int(one.counters[0].item())) / np.float64(3000) * 100.0)
+    expect = float(np.float64(int(one.counters[0].item())) / np.float64(3000) * 100.0)
+    res["class_probe_equal"] = sim._probe_success_probability(25, 3000) == expect
+    sim.shard_min_paths = 1_000_000  # default: small batches are replicated on every rank, no communication
+    res["class_probe_equal"] = res["class_probe_equal"] and sim._probe_success_probability(25, 3000) == expect
+    rep = sim.run_monte_carlo_simulations(wm, 700)
+    sim2 = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
+    sim2.shard_min_paths = 0
+    sim2.use_search_seeds()
+    shd = sim2.run_monte_carlo_simulations(wm, 700)
+    res["class_replicated_equals_sharded"] = bool(rep[0].equals(shd[0]) and np.array_equal(rep[1].to_numpy(), shd[1].to_numpy(), equal_nan=True)
+                                                  and rep[6] == shd[6] and rep[2] == shd[2])
     with open(f"{out_path}.{rank}", "w") as fh:
         json.dump(res, fh)
     dist.barrier()
