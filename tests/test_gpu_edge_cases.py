@@ -194,3 +194,6 @@ def test_very_large_batches_use_64bit_addressing(oracle):
     assert tq.shape == (b.sizes.trajectory_len, 7) and np.all(np.diff(tq, axis=1) >= 0)
     assert wc[0] == n and np.all(np.diff(wc) <= 0)
     assert tq[0].tolist() == [cfgd["initial_balance"]] * 7
+    # the 100-bin histogram of successful final balances accounts for every successful path
+    bins, edges = A.success_histogram(b.summary["final_balance"], b.success, 100)
+    assert int(bins.sum()) == int(b.counters[0].item()) and len(edges) == 101 and np.all(np.diff(edges) > 0)

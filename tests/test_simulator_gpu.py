@@ -252,3 +252,25 @@ def test_integration_md_ctypes_stub_runs_verbatim():
             assert got[k] == pytest.approx(exp[k], rel=1e-9, abs=1e-6)
         np.testing.assert_allclose(got["Trajectory"], exp["Trajectory"], rtol=1e-9, atol=1e-6)
         np.testing.assert_allclose(got["WithdrawalRateTrajectory"], exp["WithdrawalRateTrajectory"], rtol=1e-9, equal_nan=True)
+
+
+def test_search_at_50k_paths_per_probe_has_its_defining_properties():
+    """BASELINE configs[4] size (num_simulations_search = 50 000): the month found meets the target, every
+    probed earlier month misses it, probes are memoised (no month twice), and the count-only probe of the
+    chosen month equals a full run's success probability."""
+    import json
+    import os
+
+    from conftest import REPO
+
+    with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
+        cfg = Config(**dict(json.load(fh), num_simulations_search=50_000, seed=12345))
+    sim = RetirementMonteCarloSimulator(cfg)
+    months, prob, curve = sim.find_minimum_working_months(verbose=False)
+    assert months > 0 and prob >= cfg.target_probability
+    probed = [p["working_months"] for p in curve]
+    assert len(probed) == len(set(probed))
+    assert all(p["probability"] < cfg.target_probability for p in curve if p["working_months"] < months)
+    assert months - 1 in probed  # the verification sweep tests the month just before the answer
+    full = sim._success_probability(sim.run_monte_carlo_simulations(months, 50_000)[0])
+    assert full == prob
