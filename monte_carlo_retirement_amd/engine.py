@@ -43,8 +43,12 @@ def stream_start_month_index(current_age: float, working_months: int, start_at_a
 
 
 def _as_rng(seed) -> McrRng:
-    """`seed` may be an int (Philox key) or a ready McrRng descriptor."""
-    return seed if isinstance(seed, McrRng) else N.philox_rng(int(seed))
+    """`seed` may be an int (Philox key) or a ready McrRng descriptor (copied: callers' objects are never mutated)."""
+    if isinstance(seed, McrRng):
+        dup = McrRng()
+        C.memmove(C.byref(dup), C.byref(seed), C.sizeof(McrRng))
+        return dup
+    return N.philox_rng(int(seed))
 
 
 def run_batch_host(
