@@ -147,7 +147,7 @@ def main():
         begin = (i * world + rank) * n
         batch.launch(12345, 1, begin)
         if world > 1:
-            dist.all_reduce(batch.counters)  # the path's single exchange step (sum of counters)
+            dist.all_reduce(batch.reduce_vec)  # the path's single exchange step: counters + year bins, summed
 
     def fence():
         if world > 1:
@@ -167,7 +167,7 @@ def main():
         batch.launch(12345, 1, ((args.warmup + i) * world + rank) * n)
         ev[i][1].record()
         if world > 1:
-            dist.all_reduce(batch.counters)
+            dist.all_reduce(batch.reduce_vec)
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -204,7 +204,7 @@ def main():
                             f"{n} paths per GPU per step, success-count only (no trajectory writeback)",
                 "paths_per_gpu_per_step": n,
                 "rng": "Philox4x32-10 + Box-Muller, counter=(path,month,stream), key=seed",
-                "parallelism": f"path-range sharding x{world}" + (" + 1 all-reduce(sum) of counters per step" if world > 1 else ""),
+                "parallelism": f"path-range sharding x{world}" + (" + 1 all-reduce(sum) of the counter/bin vector per step" if world > 1 else ""),
             },
             "roofline": {
                 "kernel": "mcr::path_kernel<0>",

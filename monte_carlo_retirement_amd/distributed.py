@@ -177,7 +177,7 @@ def run_sharded_bands(params, rng_or_seed, stream_id: int, n_total: int, working
     if count > 0:
         batch.launch(rng_or_seed, stream_id, begin, count)
     ry = batch.sizes.retirement_years
-    vec = torch.cat([batch.counters, batch.wr_obs_counts, batch.ruin_year_bins])
+    vec = batch.reduce_vec
     if world > 1:
         all_reduce_sum_(vec)
     red = unpack_counts(vec.cpu().numpy(), ry)

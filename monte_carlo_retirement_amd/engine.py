@@ -185,9 +185,13 @@ class DeviceBatch:
         dev = torch.device("cuda", self.device)
         self.stride = (self.n_paths + 63) // 64 * 64
         f64, i64 = torch.float64, torch.int64
-        self.counters = torch.zeros(N.MCR_N_COUNTERS, dtype=i64, device=dev)
-        self.wr_obs_counts = torch.zeros(self.sizes.retirement_years, dtype=i64, device=dev)
-        self.ruin_year_bins = torch.zeros(self.sizes.ruin_bins, dtype=i64, device=dev)
+        # counters | wr_obs_counts | ruin_year_bins live in ONE int64 vector: the path's single exchange step
+        # across GPUs is one all-reduce(sum) of it
+        ry_ = self.sizes.retirement_years
+        self.reduce_vec = torch.zeros(N.MCR_N_COUNTERS + ry_ + self.sizes.ruin_bins, dtype=i64, device=dev)
+        self.counters = self.reduce_vec[:N.MCR_N_COUNTERS]
+        self.wr_obs_counts = self.reduce_vec[N.MCR_N_COUNTERS:N.MCR_N_COUNTERS + ry_]
+        self.ruin_year_bins = self.reduce_vec[N.MCR_N_COUNTERS + ry_:]
         self.summary = {}
         self.success = None
         self.trajectory = self.real_trajectory = self.withdrawal_rate_trajectory = None
@@ -221,9 +225,7 @@ class DeviceBatch:
         self._lib = N.load_library()
 
     def zero_counters(self) -> None:
-        self.counters.zero_()
-        self.wr_obs_counts.zero_()
-        self.ruin_year_bins.zero_()
+        self.reduce_vec.zero_()
 
     def launch(self, seed, stream_id: int, path_begin: int, n_paths: Optional[int] = None) -> None:
         """Enqueue one kernel launch over ``n_paths`` (default: the whole batch) on the current stream.
