@@ -33,7 +33,8 @@ struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
     int group_of[kRqMaxT];
     int n_targets, n_groups;
     unsigned int cand_count;             // keys appended to the (rank-local) candidate buffer in pass 3
-    unsigned int pad_;
+    unsigned int const_row;              // 1: every non-NaN entry of the row is the same value (done after pass 0)
+    unsigned long long kmin, kmax;       // min / max key of the row (pass 0; only when the shortcut is enabled)
 };
 // Scratch layout: RqRow[n_rows] | hist u32[n_rows][kRqMaxT][256] | aux u32[n_rows][2] | cand u64[n_rows][cap].
 // hist|aux is ONE dense block of 32-bit counters: a multi-GPU caller sums it across ranks after every
@@ -78,7 +79,7 @@ template <bool FIRST, bool COMPACT>
 __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restrict__ rows, int64_t row_stride,
                                                           int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                           unsigned int* aux, unsigned long long* cand,
-                                                          unsigned int cand_cap, int only_overflowed) {
+                                                          unsigned int cand_cap, int only_overflowed, int track_minmax) {
     extern __shared__ __align__(16) unsigned int lh[];  // [max groups of this call][256], sized by the host
     __shared__ unsigned long long lpref[kRqMaxT];
     __shared__ unsigned int lnan;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     __shared__ unsigned int stage_n, stage_base;
     const int row = blockIdx.y;
     if (only_overflowed && !aux[2 * row + 1]) return;  // slow path only for rows whose candidates overflowed
+    if (!FIRST && st[row].const_row) return;           // all-equal row: finished after pass 0
     const int G = FIRST ? 1 : st[row].n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     const double* r = rows + (int64_t)row * row_stride;
     const int shift_digit = 56 - 8 * pass;
     unsigned int my_nan = 0;
+    unsigned long long my_min = ~0ull, my_max = 0ull;  // FIRST + track_minmax: this lane's key range
     const bool vec2 = ((row_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
     const int64_t n_pairs = vec2 ? n / 2 : 0;
     unsigned long long* crow = COMPACT ? cand + (size_t)row * cand_cap : nullptr;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
         const unsigned long long k = key_of(x);
         const unsigned int digit = (unsigned int)(k >> shift_digit) & 0xFFu;
         bool active = in_range && !isnan_x;
+        if (FIRST && active) { my_min = k < my_min ? k : my_min; my_max = k > my_max ? k : my_max; }
         unsigned int key = digit;
         if (!FIRST) {
             const unsigned long long hk = k >> (shift_digit + 8);
@@ -173,6 +177,14 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock)
         if (lh[k]) atomicAdd(&gh[k], lh[k]);
     if (FIRST && threadIdx.x == 0 && lnan) atomicAdd(&aux[2 * row], lnan);
+    if (FIRST && track_minmax) {  // wave reduce, then one pair of global atomics per wave
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long omin = __shfl_down(my_min, off, 64), omax = __shfl_down(my_max, off, 64);
+            my_min = omin < my_min ? omin : my_min;
+            my_max = omax > my_max ? omax : my_max;
+        }
+        if ((threadIdx.x & 63) == 0 && my_min <= my_max) { atomicMin(&st[row].kmin, my_min); atomicMax(&st[row].kmax, my_max); }
+    }
     if (COMPACT) {  // flush the stage: one global reservation per workgroup, coalesced copy
         const unsigned int cnt = stage_n < (unsigned int)kStage ? stage_n : (unsigned int)kStage;
         if (threadIdx.x == 0) stage_base = cnt ? atomicAdd(&st[row].cand_count, cnt) : 0u;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow*
     __shared__ unsigned long long lpref[kRqMaxT];
     const int row = blockIdx.y;
     RqRow& S = st[row];
-    if (aux[2 * row + 1]) return;
+    if (aux[2 * row + 1] || S.const_row) return;
     const int G = S.n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = S.prefix[threadIdx.x];
@@ -253,8 +265,18 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
         S.n_targets = nt;
         S.n_groups = 1;
         S.prefix[0] = 0ull;
+        // all non-NaN entries equal (e.g. the t = 0 rows: every path starts from the same balance): every order
+        // statistic is that value — finish now; later passes skip the row (only when min/max were tracked)
+        S.const_row = (m > 0 && S.kmin == S.kmax) ? 1u : 0u;
     }
     __syncthreads();
+    if (S.const_row) {
+        if (pass == 0) {
+            for (int k = t; k < 256; k += 64) gh[k] = 0u;
+            if (t < args.n_q) out[(size_t)row * args.n_q + t] = value_of(S.kmin);  // lerp(a, a, g) = a
+        }
+        return;
+    }
     const int nt = S.n_targets;
     if (t < nt) {
         const int g = S.group_of[t];
@@ -316,7 +338,8 @@ __global__ void rq_init_kernel(RqRow* st, unsigned int* hist, int n_rows) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_rows) {
         st[r].n_valid = 0ull; st[r].n_targets = 0; st[r].n_groups = 1; st[r].prefix[0] = 0ull;
-        st[r].cand_count = 0u;
+        st[r].cand_count = 0u; st[r].const_row = 0u;
+        st[r].kmin = ~0ull; st[r].kmax = 0ull;  // kmin > kmax: "not tracked" (never equal)
     }
 }
 
@@ -463,8 +486,17 @@ int mcr_row_quantiles_begin(void* scratch, int32_t n_rows, int device, void* hip
     return MCR_OK;
 }
 
+static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
+                        int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax);
+
 int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
                            int32_t pass, void* scratch, int device, void* hip_stream) {
+    // rows sharded across ranks: no all-equal-row shortcut (a row's min/max is not summable across ranks)
+    return rq_hist_step(rows, row_stride, n_rows, n_local, n_q, pass, scratch, device, hip_stream, 0);
+}
+
+static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
+                        int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax) {
     int rc = use_device(device);
     if (rc != MCR_OK) return rc;
     rc = rq_check(scratch, n_rows, n_local, n_q);
@@ -485,14 +517,14 @@ int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_row
         const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);  // <= 2 targets per quantile
         const size_t lds_first = 256 * sizeof(unsigned int);
         if (pass == 0) {
-            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0);
+            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, track_minmax);
         } else if (pass < 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0);
         } else if (pass == 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0);
+            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0);
         } else {
             hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, n_rows), block, lds_groups, s, pass, L.st, L.hist, L.aux, L.cand, cap);
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1, 0);
         }
     }
     if (pass == 3) hipLaunchKernelGGL(rq_flag_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, L.st, L.aux, n_rows, cap);
@@ -528,7 +560,7 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     if (!rows || n <= 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     int rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
     for (int pass = 0; pass < 8 && rc == MCR_OK; ++pass) {
-        rc = mcr_row_quantiles_hist(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream);
+        rc = rq_hist_step(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream, /*track_minmax=*/1);
         if (rc == MCR_OK) rc = mcr_row_quantiles_scan(n_rows, n, q, n_q, pass, out, counts, scratch, device, hip_stream);
     }
     return rc;
