@@ -48,6 +48,7 @@ struct DevParams {
     int32_t num_working_years, trajectory_len, n_streams, n_lock_slots;
     int32_t contrib_grows;             // contribution_growth_rate_annual > 0        (:516)
     int32_t any_annual_tax;            // annual_rate1 > 0 || annual_rate2 > 0
+    int32_t any_real_rate;             // real_rate1 > 0 || real_rate2 > 0  -> selects the TAXED kernel variant
     DevStream streams[MCR_MAX_STREAMS];
 };
 
@@ -147,29 +148,45 @@ __device__ __forceinline__ double monthly_gross(double a, double b, double z, co
 // provable no-ops — identical results on every reachable state, ~3 % fewer VALU instructions.
 
 // _net_liquidation_value (:256-272); rate = realized rate if that system applies else 0.0.
-template <bool STRICT = true>
+// TAXED = false is the compile-time variant for scenarios in which NEITHER asset has an effective
+// realized-gains rate (the reference's DEFAULT configuration, config.py:74-75,80-81).  With rate == 0 every
+// product with it is exactly +0, t / 1 = t, so the untaxed forms are bit-identical to the general ones and
+// skip the dead arithmetic (two of the three divisions in withdraw / rebalance): +13 % paths/s there.
+// (A run-time branch instead cost the taxed kernel 4 %, hence a template parameter.)
+template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ double net_liquidation_value(double bal, double cb, double rate) {
-    const double tax = fmax(0.0, bal - cb) * rate;
-    const double v = STRICT ? fmax(0.0, bal - tax) : bal - tax;  // tax <= bal when cb >= 0, rate <= 1
+    double v = bal;  // rate == 0: tax = 0, max(0, bal - 0) = bal for bal > eps
+    if (TAXED) {
+        const double tax = fmax(0.0, bal - cb) * rate;
+        v = STRICT ? fmax(0.0, bal - tax) : bal - tax;  // tax <= bal when cb >= 0, rate <= 1
+    }
     return bal <= kEps ? 0.0 : v;
 }
 
 // _calculate_withdrawal_and_update (:201-254), branch-free.
-template <bool STRICT = true>
+template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
                                          double& gross_out, double& net_out) {
     const bool skip = (bal <= kEps) || (net_target <= 0.0);              // :218
     const double inv_bal = recip_nr(bal);                                // shared by the two divisions by bal
-    const double gain_fraction = div_by(fmax(0.0, bal - cb), bal, inv_bal);  // :221
-    const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
-    const double gross = fmin(fdiv(net_target, net_fraction), bal);      // :228-231
+    double gross;
+    if (TAXED) {
+        const double gain_fraction = div_by(fmax(0.0, bal - cb), bal, inv_bal);  // :221
+        const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
+        gross = fmin(fdiv(net_target, net_fraction), bal);               // :228-231
+    } else {
+        gross = fmin(net_target, bal);                                   // net_fraction = max(eps, 1 - g*0) = 1; t / 1 = t
+    }
     const double sold = div_by(gross, bal, inv_bal);
     const double fraction_sold = STRICT ? fmin(1.0, sold) : sold;        // :233  (gross <= bal)
     const double basis_part = cb * fraction_sold;
     const double basis_removed = STRICT ? fmin(cb, basis_part) : basis_part;  // :234  (fraction <= 1, cb >= 0)
-    const double taxable_gain = fmax(0.0, gross - basis_removed);        // :235
-    const double tax_paid = taxable_gain * rate;                         // :236-240
-    const double net_cash = STRICT ? fmax(0.0, gross - tax_paid) : gross - tax_paid;  // :241 (tax <= gross)
+    double net_cash = gross;                                             // rate == 0: tax_paid = 0, max(0, gross) = gross
+    if (TAXED) {
+        const double taxable_gain = fmax(0.0, gross - basis_removed);    // :235
+        const double tax_paid = taxable_gain * rate;                     // :236-240
+        net_cash = STRICT ? fmax(0.0, gross - tax_paid) : gross - tax_paid;  // :241 (tax <= gross)
+    }
     double nb = STRICT ? fmax(0.0, bal - gross) : bal - gross;           // :243
     double ncb = STRICT ? fmax(0.0, cb - basis_removed) : cb - basis_removed;  // :244
     const bool dust = nb <= kEps;                                        // :245-247
@@ -182,7 +199,7 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
 }
 
 // _rebalance_portfolio (:274-359), branch-free: the over-weight asset is the seller.
-template <bool STRICT = true>
+template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, double& c1, double& b2,
                                           double& c2) {
     const double total = b1 + b2;                                  // :288
@@ -199,16 +216,24 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     const double alloc_s = sell1 ? P.alloc1 : P.alloc2;            // the SOLD asset's own weight (:309,:337)
     const double rate_s = sell1 ? P.real_rate1 : P.real_rate2;
     const double inv_bs = recip_nr(bs);                            // shared by the two divisions by bs
-    const double gain_fraction = div_by(fmax(0.0, bs - cs), bs, inv_bs);  // :301 / :329
-    const double tax_per_dollar = gain_fraction * rate_s;          // :302-306
-    const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
-    const double gross_sale = fmin(bs, fdiv(drift, denom));        // :311
+    double gross_sale;
+    if (TAXED) {
+        const double gain_fraction = div_by(fmax(0.0, bs - cs), bs, inv_bs);  // :301 / :329
+        const double tax_per_dollar = gain_fraction * rate_s;      // :302-306
+        const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
+        gross_sale = fmin(bs, fdiv(drift, denom));                 // :311
+    } else {
+        gross_sale = fmin(bs, drift);                              // tax_per_dollar = 0, denom = 1, drift / 1 = drift
+    }
     const double fraction_sold = div_by(gross_sale, bs, inv_bs);   // :312
     const double basis_part = cs * fraction_sold;
     const double basis_removed = STRICT ? fmin(cs, basis_part) : basis_part;  // :313 (gross_sale <= bs, cs >= 0)
-    const double taxable_gain = fmax(0.0, gross_sale - basis_removed);  // :314
-    const double tax_paid = taxable_gain * rate_s;                 // :315-319
-    const double net_purchase = gross_sale - tax_paid;             // :320
+    double net_purchase = gross_sale;                              // rates 0: tax_paid = 0
+    if (TAXED) {
+        const double taxable_gain = fmax(0.0, gross_sale - basis_removed);  // :314
+        const double tax_paid = taxable_gain * rate_s;             // :315-319
+        net_purchase = gross_sale - tax_paid;                      // :320
+    }
     double nbs = STRICT ? fmax(0.0, bs - gross_sale) : bs - gross_sale;        // :322
     double ncs = STRICT ? fmax(0.0, cs - basis_removed) : cs - basis_removed;  // :323
     double nbb = bb + net_purchase;                                // :324
@@ -227,7 +252,7 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
 }
 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
-template <bool STRICT = true>
+template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
@@ -235,8 +260,8 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
         const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
         const double total_due = due1 + due2;                         // :390
-        const double cap1 = net_liquidation_value<STRICT>(b1, c1, L.real_rate1);  // :392-397
-        const double cap2 = net_liquidation_value<STRICT>(b2, c2, L.real_rate2);  // :398-403
+        const double cap1 = net_liquidation_value<STRICT, TAXED>(b1, c1, L.real_rate1);  // :392-397
+        const double cap2 = net_liquidation_value<STRICT, TAXED>(b2, c2, L.real_rate2);  // :398-403
         const double cap = cap1 + cap2;                               // :404
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
@@ -244,12 +269,12 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
             const double share1 = fdiv(cap1, cap);                    // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
-            withdraw<STRICT>(b1, c1, pay * share1, L.real_rate1, g, net1);    // :411-419
-            withdraw<STRICT>(b2, c2, pay * share2, L.real_rate2, g, net2);    // :420-428
+            withdraw<STRICT, TAXED>(b1, c1, pay * share1, L.real_rate1, g, net1);  // :411-419
+            withdraw<STRICT, TAXED>(b2, c2, pay * share2, L.real_rate2, g, net2);  // :420-428
             tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
         }
     }
-    rebalance<STRICT>(L, b1, c1, b2, c2);  // :432-442 (always)
+    rebalance<STRICT, TAXED>(L, b1, c1, b2, c2);  // :432-442 (always)
     return tax_failed;
 }
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 
 // __launch_bounds__(256, 4): the kernel saturates the fp64 VALU with 4 waves per SIMD (measured by capping
 // residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.
-template <int MODE, int RNG>
+template <int MODE, int RNG, bool TAXED>
 __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, const KernelIO io) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS: math tables (mcr_math.h), [numpy ziggurat tables], [n_lock_slots][kBlock] doubles (frozen
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance<false>(L, b1, c1, b2, c2);                           // :549-553
+        rebalance<false, TAXED>(L, b1, c1, b2, c2);                    // :549-553
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes<false>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes<false, TAXED>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -194,23 +194,23 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     }
                 }
                 if (!stop) {
-                    const double cap1 = net_liquidation_value<false>(b1, c1, L.real_rate1);  // :726-731
-                    const double cap2 = net_liquidation_value<false>(b2, c2, L.real_rate2);  // :732-737
+                    const double cap1 = net_liquidation_value<false, TAXED>(b1, c1, L.real_rate1);  // :726-731
+                    const double cap2 = net_liquidation_value<false, TAXED>(b2, c2, L.real_rate2);  // :732-737
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmax(0.0, fmin(need, cap));                 // :739-742
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
                     const double prop1 = cap > kEps ? fdiv(cap1, cap) : P.alloc1;     // :750-754
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
-                    withdraw<false>(b1, c1, target * prop1, L.real_rate1, gw1, nw1);  // :757-765
+                    withdraw<false, TAXED>(b1, c1, target * prop1, L.real_rate1, gw1, nw1);  // :757-765
                     tg1 += gw1;                                                       // :766
-                    withdraw<false>(b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
+                    withdraw<false, TAXED>(b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg2 += gw2;                                                       // :777
                     if (kSummary) treal += fdiv((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance<false>(L, b1, c1, b2, c2);                              // :792-796
+                    rebalance<false, TAXED>(L, b1, c1, b2, c2);                       // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
-                        const bool tf = annual_gain_taxes<false>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        const bool tf = annual_gain_taxes<false, TAXED>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
                         yfail = yfail || tf;                                          // :821-822
                     }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes<false>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            const bool tf = annual_gain_taxes<false, TAXED>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
             if (tf) { succeeded = false; ytr_bits = f64_bits((double)ry); ruin_bin = ry + 1; }  // :894-896
             put_sample(P.trajectory_len - 1, b1 + b2, infl);                     // :897-898
         }
@@ -471,6 +471,7 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     d->annual_rate1 = !p->inv1_use_realized_gains_tax_system ? p->inv1_annual_tax_on_gains_rate : 0.0;  // :380-384
     d->annual_rate2 = !p->inv2_use_realized_gains_tax_system ? p->inv2_annual_tax_on_gains_rate : 0.0;  // :385-389
     d->any_annual_tax = (d->annual_rate1 > 0.0) || (d->annual_rate2 > 0.0);
+    d->any_real_rate = (d->real_rate1 > 0.0) || (d->real_rate2 > 0.0);
     const double sqrt12 = std::sqrt((double)kMPY);
     d->a1 = p->inv1_mu_log / (double)kMPY;   d->b1 = p->inv1_sigma_log / sqrt12;     // :473
     d->ainf = p->inf_mu_log / (double)kMPY;  d->binf = p->inf_sigma_log / sqrt12;
@@ -560,15 +561,20 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     if (lds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
+    // kernel variant: output mode x RNG x (any effective realized-gains rate?)
+#define MCR_LAUNCH(M, R, T) hipLaunchKernelGGL((path_kernel<M, R, T>), grid, block, lds, stream, d, io)
+#define MCR_LAUNCH_T(M, R) do { if (d.any_real_rate) MCR_LAUNCH(M, R, true); else MCR_LAUNCH(M, R, false); } while (0)
     if (!np_rng) {
-        if (mode == 2) hipLaunchKernelGGL((path_kernel<2, 0>), grid, block, lds, stream, d, io);
-        else if (mode == 1) hipLaunchKernelGGL((path_kernel<1, 0>), grid, block, lds, stream, d, io);
-        else hipLaunchKernelGGL((path_kernel<0, 0>), grid, block, lds, stream, d, io);
+        if (mode == 2) MCR_LAUNCH_T(2, 0);
+        else if (mode == 1) MCR_LAUNCH_T(1, 0);
+        else MCR_LAUNCH_T(0, 0);
     } else {
-        if (mode == 2) hipLaunchKernelGGL((path_kernel<2, 1>), grid, block, lds, stream, d, io);
-        else if (mode == 1) hipLaunchKernelGGL((path_kernel<1, 1>), grid, block, lds, stream, d, io);
-        else hipLaunchKernelGGL((path_kernel<0, 1>), grid, block, lds, stream, d, io);
+        if (mode == 2) MCR_LAUNCH_T(2, 1);
+        else if (mode == 1) MCR_LAUNCH_T(1, 1);
+        else MCR_LAUNCH_T(0, 1);
     }
+#undef MCR_LAUNCH_T
+#undef MCR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "path_kernel launch");
     return MCR_OK;
