@@ -207,7 +207,7 @@ def main():
                 "parallelism": f"path-range sharding x{world}" + (" + 1 all-reduce(sum) of the counter/bin vector per step" if world > 1 else ""),
             },
             "roofline": {
-                "kernel": "mcr::path_kernel<0, 0, true>  (MODE 0 count-only, Philox, taxed variant)",
+                "kernel": "mcr::path_kernel<0, 0, true, false>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
                 "bound": "valu_fp64",
                 "achieved": achieved_t,
                 "peak": FP64_LANE_OPS_PEAK_T,

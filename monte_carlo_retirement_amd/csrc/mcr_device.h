@@ -252,11 +252,13 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
 }
 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
-template <bool STRICT = true, bool TAXED = true>
+// ANNUAL = false: compile-time variant for scenarios in which no asset is on the annual-gains system (annual
+// bill identically 0, :380-390): the block below and the monthly gain accumulators are dead code.
+template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
-    if (P.any_annual_tax) {  // wave-uniform: with no annual-tax asset the bill is 0 (:380-390)
+    if (ANNUAL && P.any_annual_tax) {  // wave-uniform: with no annual-tax asset the bill is 0 (:380-390)
         const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
         const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
         const double total_due = due1 + due2;                         // :390
@@ -279,6 +281,7 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
 }
 
 // Market step shared by both phases (:522-538 and :695-714).
+template <bool ANNUAL = true>
 __device__ __forceinline__ void market_step(const DevParams& P, const double* tab, double z_eq,
                                             double z_inf, double z_prem, double& b1, double& b2,
                                             double& gacc1, double& gacc2, double& infl) {
@@ -286,8 +289,10 @@ __device__ __forceinline__ void market_step(const DevParams& P, const double* ta
     const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab);
     const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab);
     const double g2 = ginf * gprem;   // :532
-    gacc1 += b1 * (g1 - 1.0);         // :534
-    gacc2 += b2 * (g2 - 1.0);         // :535
+    if (ANNUAL) {                     // the accumulators only feed the annual tax bill
+        gacc1 += b1 * (g1 - 1.0);     // :534
+        gacc2 += b2 * (g2 - 1.0);     // :535
+    }
     b1 *= g1;                         // :536
     b2 *= g2;                         // :537
     infl *= ginf;                     // :538

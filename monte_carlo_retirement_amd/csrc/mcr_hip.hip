@@ -54,7 +54,7 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 
 // __launch_bounds__(256, 4): the kernel saturates the fp64 VALU with 4 waves per SIMD (measured by capping
 // residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.
-template <int MODE, int RNG, bool TAXED>
+template <int MODE, int RNG, bool TAXED, bool ANNUAL>
 __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, const KernelIO io) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS: math tables (mcr_math.h), [numpy ziggurat tables], [n_lock_slots][kBlock] doubles (frozen
@@ -132,13 +132,13 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
         if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) contrib *= P.contrib_growth_factor;  // :514-517
         double ze, zi, zp;
         shocks(m - 1, ze, zi, zp);                                     // :519-520
-        market_step(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);   // :522-538
+        market_step<ANNUAL>(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);   // :522-538
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
         rebalance<false, TAXED>(L, b1, c1, b2, c2);                    // :549-553
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes<false, TAXED>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                 if (!stop) {
                     double ze, zi, zp;
                     shocks(wm + rmi, ze, zi, zp);                      // :692-693
-                    market_step(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
+                    market_step<ANNUAL>(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
                     if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
                         b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
                         yfail = true; stop = true;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
                     rebalance<false, TAXED>(L, b1, c1, b2, c2);                       // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
-                        const bool tf = annual_gain_taxes<false, TAXED>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        const bool tf = annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
                         yfail = yfail || tf;                                          // :821-822
                     }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes<false, TAXED>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            const bool tf = annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
             if (tf) { succeeded = false; ytr_bits = f64_bits((double)ry); ruin_bin = ry + 1; }  // :894-896
             put_sample(P.trajectory_len - 1, b1 + b2, infl);                     // :897-898
         }
@@ -561,9 +561,13 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     if (lds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
-    // kernel variant: output mode x RNG x (any effective realized-gains rate?)
-#define MCR_LAUNCH(M, R, T) hipLaunchKernelGGL((path_kernel<M, R, T>), grid, block, lds, stream, d, io)
-#define MCR_LAUNCH_T(M, R) do { if (d.any_real_rate) MCR_LAUNCH(M, R, true); else MCR_LAUNCH(M, R, false); } while (0)
+    // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?)
+#define MCR_LAUNCH(M, R, T, A) hipLaunchKernelGGL((path_kernel<M, R, T, A>), grid, block, lds, stream, d, io)
+#define MCR_LAUNCH_T(M, R)                                                                         \
+    do {                                                                                           \
+        if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH(M, R, true, true); else MCR_LAUNCH(M, R, true, false); } \
+        else { if (d.any_annual_tax) MCR_LAUNCH(M, R, false, true); else MCR_LAUNCH(M, R, false, false); }               \
+    } while (0)
     if (!np_rng) {
         if (mode == 2) MCR_LAUNCH_T(2, 0);
         else if (mode == 1) MCR_LAUNCH_T(1, 0);
