@@ -199,6 +199,21 @@ int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng, uint32_t str
 int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                              int32_t n_months, double rho, double* out, int device);
 
+/*
+ * Search driver support (find_minimum_working_months, simulation.py:1138-1342): success counts of
+ * SEVERAL candidate working-month counts over the same path range — what the reference obtains by
+ * calling run_monte_carlo_simulations(candidate, num_simulations_search) once per candidate and taking
+ * _success_probability of each summary (simulation.py:1186-1199).  One count-only launch per candidate,
+ * forked onto internal HIP streams so the candidates share the GPU concurrently (a 50 000-path probe
+ * fills under a fifth of the chip), joined back onto `hip_stream`; asynchronous like mcr_run_batch.
+ * counts: DEVICE uint64 [n_candidates][MCR_N_COUNTERS] = {successes, paths} per candidate (zeroed by
+ * the call).  Common random numbers across candidates hold as in the reference (same path range, same
+ * stream).
+ */
+int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                         uint64_t n_paths, const int32_t* working_months, int32_t n_candidates,
+                         uint64_t* counts, int device, void* hip_stream);
+
 /* _draw_shock_path (simulation.py:452-466) for n_paths paths: host out [n_paths][n_months][3]. */
 int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
                          uint64_t n_paths, int32_t n_months, double rho, double* out,

@@ -171,6 +171,7 @@ ABI_SYMBOLS = (
     "mcr_run_batch_rng",
     "mcr_run_batch_host_rng",
     "mcr_draw_shocks_host_rng",
+    "mcr_probe_months_rng",
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
@@ -222,6 +223,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.mcr_run_batch_rng.argtypes = [
         P(McrParams), P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
         C.c_void_p, P(McrOutputs), C.c_int, C.c_void_p,
+    ]
+    lib.mcr_probe_months_rng.restype = C.c_int
+    lib.mcr_probe_months_rng.argtypes = [
+        P(McrParams), P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, P(C.c_int32), C.c_int32,
+        C.c_void_p, C.c_int, C.c_void_p,
     ]
     lib.mcr_run_batch_host_rng.restype = C.c_int
     lib.mcr_run_batch_host_rng.argtypes = [

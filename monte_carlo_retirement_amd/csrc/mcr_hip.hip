@@ -20,6 +20,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "mcr_device.h"
@@ -626,6 +627,74 @@ int mcr_run_batch_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_i
     if (rc != MCR_OK) return rc;
     return launch_paths(p, rng, stream_id, path_begin, n_paths, working_months, injected_shocks, out,
                         (hipStream_t)hip_stream);
+}
+
+// Fork/join helper for mcr_probe_months_rng: a few non-blocking side streams per (thread, device), created on
+// first use and kept for the life of the process (destroying HIP objects from thread-exit hooks is not safe).
+namespace {
+constexpr int kProbeStreams = 8;
+struct ProbeFork {
+    hipStream_t side[kProbeStreams];
+    hipEvent_t done[kProbeStreams];
+    hipEvent_t fork;
+};
+ProbeFork* probe_fork(int device) {
+    static thread_local std::vector<std::pair<int, ProbeFork*>> pools;
+    for (auto& pr : pools) if (pr.first == device) return pr.second;
+    ProbeFork* f = new ProbeFork();
+    bool ok = hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < kProbeStreams; ++i)
+        ok = hipStreamCreateWithFlags(&f->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&f->done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); delete f; return nullptr; }   // partial objects leak: out-of-resources path only
+    pools.emplace_back(device, f);
+    return f;
+}
+}  // namespace
+
+int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                         uint64_t n_paths, const int32_t* working_months, int32_t n_candidates,
+                         uint64_t* counts, int device, void* hip_stream) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    if (!working_months || !counts || n_candidates < 0) { set_error("null candidates / counts"); return MCR_ERR_INVALID_ARG; }
+    if (n_candidates == 0) return MCR_OK;
+    // validate every candidate BEFORE enqueueing anything, so a bad one leaves no half-forked work behind
+    for (int32_t c = 0; c < n_candidates; ++c) {
+        DevParams d;
+        rc = derive_params(p, working_months[c], &d);
+        if (rc != MCR_OK) return rc;
+    }
+    rc = check_rng(rng);
+    if (rc != MCR_OK) return rc;
+    hipStream_t main = (hipStream_t)hip_stream;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint64_t) * MCR_N_COUNTERS * (size_t)n_candidates, main);
+    if (e != hipSuccess) return hip_fail(e, "probe counters memset");
+    if (n_candidates == 1) {
+        mcr_outputs o;
+        std::memset(&o, 0, sizeof(o));
+        o.counters = counts;
+        return launch_paths(p, rng, stream_id, path_begin, n_paths, working_months[0], nullptr, &o, main);
+    }
+    ProbeFork* f = probe_fork(device);
+    if (!f) { set_error("could not create probe streams"); return MCR_ERR_HIP; }
+    const int used = n_candidates < kProbeStreams ? n_candidates : kProbeStreams;
+    if ((e = hipEventRecord(f->fork, main)) != hipSuccess) return hip_fail(e, "probe fork");
+    for (int i = 0; i < used; ++i)
+        if ((e = hipStreamWaitEvent(f->side[i], f->fork, 0)) != hipSuccess) return hip_fail(e, "probe fork wait");
+    int first_rc = MCR_OK;
+    for (int32_t c = 0; c < n_candidates && first_rc == MCR_OK; ++c) {
+        mcr_outputs o;
+        std::memset(&o, 0, sizeof(o));
+        o.counters = counts + (size_t)c * MCR_N_COUNTERS;
+        first_rc = launch_paths(p, rng, stream_id, path_begin, n_paths, working_months[c], nullptr, &o, f->side[c % used]);
+    }
+    // always join, also after a failed launch: `main` must not run ahead of work already forked
+    for (int i = 0; i < used; ++i) {
+        if ((e = hipEventRecord(f->done[i], f->side[i])) != hipSuccess) return hip_fail(e, "probe join record");
+        if ((e = hipStreamWaitEvent(main, f->done[i], 0)) != hipSuccess) return hip_fail(e, "probe join wait");
+    }
+    return first_rc;
 }
 
 int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id, uint64_t path_begin,

@@ -240,3 +240,27 @@ class DeviceBatch:
             self.working_months, None, C.byref(self._out), self.device, C.c_void_p(stream),
         )
         N.check(rc, "mcr_run_batch_rng")
+
+
+def probe_months(params: McrParams, seed, stream_id: int, path_begin: int, n_paths: int, working_months,
+                 device: int = 0):
+    """Success counters of several candidate working-month counts over the same path range: one
+    count-only launch per candidate, run concurrently on the library's side streams (fork/join on
+    torch's current stream).  Returns a device int64 tensor ``[len(working_months), 2]`` =
+    ``{successes, paths}``; asynchronous (reading it synchronises)."""
+    import torch
+
+    N.require_device()
+    months = (C.c_int32 * len(working_months))(*[int(m) for m in working_months])
+    counts = torch.empty((len(working_months), N.MCR_N_COUNTERS), dtype=torch.int64,
+                         device=torch.device("cuda", int(device)))
+    if len(working_months) == 0:
+        return counts
+    rng = _as_rng(seed)
+    stream = torch.cuda.current_stream(int(device)).cuda_stream
+    rc = N.load_library().mcr_probe_months_rng(
+        C.byref(params), C.byref(rng), int(stream_id), int(path_begin), int(n_paths), months,
+        len(working_months), counts.data_ptr(), int(device), C.c_void_p(stream),
+    )
+    N.check(rc, "mcr_probe_months_rng")
+    return counts

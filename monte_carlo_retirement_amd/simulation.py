@@ -19,7 +19,7 @@ What differs, by design (documented in DESIGN.md):
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Optional, Tuple, Union
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import pandas as pd
@@ -478,24 +478,60 @@ class RetirementMonteCarloSimulator:
             return float(summary_df["Success"].astype(bool).mean() * 100.0)
         return float((summary_df["Final Balance"] > SMALL_EPSILON).mean() * 100.0)
 
-    # ---- count-only probe used by the search ------------------------------------------------------
-    def _probe_success_probability(self, working_months: int, num_simulations: int) -> float:
-        """Success % of a batch from the count-only kernel (no per-path HBM traffic).  Equals
-        ``_success_probability(run_monte_carlo_simulations(...)[0])`` bit-for-bit: count/n*100."""
+    # ---- count-only probes used by the search ------------------------------------------------------
+    def _probe_many(self, months: Sequence[int], num_simulations: int) -> Dict[int, float]:
+        """Success % of several candidate working-month counts over the same paths, from count-only
+        kernels run concurrently (``mcr_probe_months_rng``).  Each value equals
+        ``_success_probability(run_monte_carlo_simulations(m, n)[0])`` bit-for-bit: count/n*100.
+
+        Under a process group: batches of at least ``shard_min_paths`` are sharded by path range (every
+        rank counts all candidates on its shard); smaller ones are split by CANDIDATE (rank r takes
+        ``months[r::world]`` over the whole range).  Either way the counter block is summed with one
+        all-reduce and every rank sees the same probabilities (and replays the same search)."""
+        import torch
+
+        months = [int(m) for m in months]
         n = int(num_simulations)
-        if D.is_active() and n >= self.shard_min_paths:
-            # one process per GPU: each rank simulates its shard of [0, n), counts are summed with a
-            # single all-reduce, every rank sees the same probability (and replays the same search)
-            params = self._current_params()
-            red = D.run_sharded_counts(
-                n, params.retirement_years,
-                D.gpu_count_runner(params, self._batch_rng(n), self._stream_id, int(working_months)),
-            )
-            return red.success_probability_pct
-        batch = E.DeviceBatch(self._current_params(), int(working_months), n, want="count", device=self._local_device())
-        batch.launch(self._batch_rng(n), self._stream_id, 0)
-        ok = int(batch.counters[N.MCR_CTR_SUCCESS].item())
-        return float(np.float64(ok) / np.float64(n) * 100.0)
+        params, rng, dev = self._current_params(), self._batch_rng(n), self._local_device()
+        if not D.is_active():
+            counts = E.probe_months(params, rng, self._stream_id, 0, n, months, device=dev)
+        else:
+            import torch.distributed as dist
+
+            rank, world = dist.get_rank(), dist.get_world_size()
+            if n >= self.shard_min_paths:
+                begin, count = D.shard_range(n, rank, world)
+                counts = E.probe_months(params, rng, self._stream_id, begin, count, months, device=dev)
+                if count == 0:
+                    counts.zero_()
+            else:
+                counts = torch.zeros((len(months), N.MCR_N_COUNTERS), dtype=torch.int64,
+                                     device=torch.device("cuda", dev))
+                mine = list(range(rank, len(months), world))
+                if mine:
+                    counts[mine] = E.probe_months(params, rng, self._stream_id, 0, n,
+                                                  [months[i] for i in mine], device=dev)
+            if dist.get_backend() != "nccl":
+                counts = counts.cpu()
+            D.all_reduce_sum_(counts)
+        ok = counts[:, N.MCR_CTR_SUCCESS].cpu().numpy()
+        return {m: float(np.float64(int(ok[i])) / np.float64(n) * 100.0) for i, m in enumerate(months)}
+
+    def _probe_success_probability(self, working_months: int, num_simulations: int) -> float:
+        """Success % of one batch from the count-only kernel (no per-path HBM traffic)."""
+        return self._probe_many([working_months], num_simulations)[int(working_months)]
+
+    def _speculation_slots(self, num_simulations: int) -> int:
+        """How many candidate months one round of the search may evaluate together at the cost of one.
+        On one GPU concurrency between candidates only buys ~25 % (measured, 50 000-path probes), less
+        than a wrong guess costs, so nothing is evaluated on speculation there (the verification window,
+        whose months are all needed, is still one batch).  When small batches are split by candidate
+        across the ranks of a process group, every rank can take one candidate for free."""
+        if D.is_active() and int(num_simulations) < self.shard_min_paths:
+            import torch.distributed as dist
+
+            return dist.get_world_size()
+        return 1
 
     # ---- search driver (:1138-1342) ------------------------------------------------------------
     def find_minimum_working_months(
@@ -521,14 +557,20 @@ class RetirementMonteCarloSimulator:
         memo: Dict[int, float] = {}
         state = {"iter": 0, "best_seen": -1.0, "lo": first, "hi": None}
         # the reference's tests (and callers) may replace run_monte_carlo_simulations per instance;
-        # then the search must go through it.  Otherwise use the count-only kernel.
+        # then the search must go through it.  Otherwise use the count-only kernels, and evaluate
+        # candidates the driver is about to ask for TOGETHER with the one it asks for now (they share
+        # the GPU concurrently / are split across ranks).  `ahead` only holds results early: months
+        # are still reported one by one, in the reference's order, and a month the reference would
+        # not have probed never reaches memo, the curve or the callback.
         patched = "run_monte_carlo_simulations" in self.__dict__
+        ahead: Dict[int, float] = {}
+        slots = 1 if patched else self._speculation_slots(n_sims)
 
         if verbose:
             logger.info(f"Estimating working months to achieve {target:.2f}% success for '{p.Nickname}'.")
             logger.info(f"Starting search from {first} months. Simulations per test: {n_sims}.")
 
-        def probe(months: int) -> float:
+        def probe(months: int, likely_next: Sequence[int] = ()) -> float:
             if months in memo:
                 return memo[months]
             state["iter"] += 1
@@ -539,7 +581,11 @@ class RetirementMonteCarloSimulator:
                 summary_df = self.run_monte_carlo_simulations(months, n_sims)[0]
                 prob = self._success_probability(summary_df)
             else:
-                prob = self._probe_success_probability(months, n_sims)
+                if months not in ahead:
+                    batch = [months] + [m for m in dict.fromkeys(likely_next)
+                                        if m != months and m not in ahead and m not in memo]
+                    ahead.update(self._probe_many(batch, n_sims))
+                prob = ahead[months]
             memo[months] = prob
             if verbose:
                 logger.info(f"  Search iter {state['iter']}: Prob for {months} m: {prob:.2f}% (Target: {target:.2f}%)")
@@ -553,6 +599,20 @@ class RetirementMonteCarloSimulator:
                 })
             state["best_seen"] = max(state["best_seen"], prob)
             return prob
+
+        def bisection_mids(lo: int, hi: int, budget: int) -> List[int]:
+            """Midpoints the bisection can reach from (lo, hi), breadth first, at most ``budget``."""
+            out: List[int] = []
+            frontier = [(lo, hi)]
+            while frontier and len(out) < budget:
+                nxt_frontier = []
+                for a, b in frontier:
+                    if b - a > 1 and len(out) < budget:
+                        mid = (a + b) // 2
+                        out.append(mid)
+                        nxt_frontier += [(a, mid), (mid, b)]
+                frontier = nxt_frontier
+            return out
 
         # phase 1: bracket
         step = 12
@@ -569,7 +629,8 @@ class RetirementMonteCarloSimulator:
             nxt = min(at + step, horizon)
             if nxt <= at:
                 break
-            prob = probe(nxt)
+            # the step never shrinks, so the following bracket points are (almost always) nxt + k*step
+            prob = probe(nxt, [min(nxt + k * step, horizon) for k in range(1, slots)])
             if prob >= target:
                 state["lo"], state["hi"], best_prob = at, nxt, prob
                 if verbose:
@@ -591,7 +652,7 @@ class RetirementMonteCarloSimulator:
         best = state["hi"]
         while state["hi"] - state["lo"] > 1:
             mid = (state["lo"] + state["hi"]) // 2
-            prob = probe(mid)
+            prob = probe(mid, bisection_mids(state["lo"], state["hi"], slots))
             if prob >= target:
                 best, best_prob = mid, prob
                 state["hi"] = mid
@@ -606,8 +667,9 @@ class RetirementMonteCarloSimulator:
         if verbose:
             logger.info(f"  Verifying each month from {verify_from} to {best} "
                         "to handle locally non-monotone Monte Carlo estimates.")
-        for month in range(verify_from, best + 1):
-            probe(month)
+        window = list(range(verify_from, best + 1))
+        for month in window:
+            probe(month, window)   # every month of the window is needed: evaluate them in one batch
         hits = [m for m, pr in memo.items() if first <= m <= best and pr >= target]
         if hits:
             best = min(hits)

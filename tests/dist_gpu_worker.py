@@ -89,6 +89,27 @@ def main():
     res["class_probe_equal"] = sim._probe_success_probability(25, 3000) == expect
     sim.shard_min_paths = 1_000_000  # default: small batches are replicated on every rank, no communication
     res["class_probe_equal"] = res["class_probe_equal"] and sim._probe_success_probability(25, 3000) == expect
+    # several candidates in one call: split by candidate (small batch) and by path range (forced) agree with
+    # the single-GPU counts
+    cands = [0, 13, 25, 31, 60]
+    solo = E.probe_months(p, 2024, 0, 0, 3000, cands, device=0)[:, 0].cpu().numpy()
+    expect_many = {m: float(np.float64(int(solo[i])) / np.float64(3000) * 100.0) for i, m in enumerate(cands)}
+    res["class_probe_many_by_candidate"] = sim._probe_many(cands, 3000) == expect_many
+    sim.shard_min_paths = 0
+    res["class_probe_many_by_range"] = sim._probe_many(cands, 3000) == expect_many
+    sim.shard_min_paths = 1_000_000
+    res["class_speculation_slots"] = sim._speculation_slots(50_000) == world and sim._speculation_slots(10**7) == 1
+    # the whole search under the group (candidates split across ranks, bracket/bisection points evaluated
+    # ahead): every rank must replay the reference's recorded search exactly
+    g = json.load(open(os.path.join(REPO, "tests", "golden", "search.json")))[0]
+    s_sim = RetirementMonteCarloSimulator(Config(**g["cfg"]), main_seed_override=g["seed"])
+    s_events, s_calls = [], []
+    s_many = s_sim._probe_many
+    s_sim._probe_many = lambda months, n: (s_calls.append(len(months)), s_many(months, n))[1]
+    s_res = s_sim.find_minimum_working_months(verbose=False, progress_callback=s_events.append)
+    res["class_search_replays_reference"] = bool(
+        s_res[0] == g["months"] and s_res[1] == g["probability"] and s_res[2] == g["search_curve"] and s_events == g["events"])
+    res["class_search_batched"] = bool(len(s_calls) < len(g["search_curve"]))
     rep = sim.run_monte_carlo_simulations(wm, 700)
     sim2 = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
     sim2.shard_min_paths = 0

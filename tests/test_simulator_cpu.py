@@ -160,3 +160,46 @@ def test_config_schema_equals_the_references():
 
     mine = strip(json.loads(json.dumps(Config.model_json_schema())))
     assert mine == load_golden("config_schema.json")
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+@pytest.mark.parametrize("slots", [1, 3, 5, 16])
+def test_search_batches_candidates_without_changing_the_replay(idx, slots):
+    """The GPU route evaluates candidates ahead of time, several per call (`_probe_many`).  With the
+    probabilities the REFERENCE measured behind a fake `_probe_many`, months/probability/curve/events
+    must still equal the reference's run for any speculation width; months the reference never probed
+    may be evaluated but must not be reported, and no month is evaluated twice."""
+    g = load_golden("search.json")[idx]
+    cfg = Config(**g["cfg"])
+    n = cfg.num_simulations_search
+    table = {e["working_months"]: e["probability"] for e in g["events"] if e["type"] == "search_iter"}
+    exact = {e["working_months"]: int(round(e["probability"] * n / 100.0)) / n * 100.0 for e in g["events"]
+             if e["type"] == "search_iter"}
+    sim = RetirementMonteCarloSimulator(cfg, main_seed_override=g["seed"])
+    calls = []
+
+    def fake_probe_many(months, k):
+        assert k == n and len(set(months)) == len(months)
+        calls.append(list(months))
+        # a month outside the reference's run gets a neutral value between its probed neighbours
+        known = sorted(exact)
+        return {m: exact.get(m, exact[min(known, key=lambda x: abs(x - m))]) for m in months}
+
+    sim._probe_many = fake_probe_many
+    sim._speculation_slots = lambda k: slots
+    events = []
+    months, prob, curve = sim.find_minimum_working_months(verbose=False, progress_callback=events.append)
+    assert months == g["months"]
+    assert prob == pytest.approx(g["probability"], abs=1e-9)
+    assert [c["working_months"] for c in curve] == [c["working_months"] for c in g["search_curve"]]
+    assert [c["probability"] for c in curve] == [round(table[c["working_months"]], 2) for c in g["search_curve"]]
+    assert [e for e in events if e["type"] != "search_iter"] == [e for e in g["events"] if e["type"] != "search_iter"]
+    assert [(e["iteration"], e["working_months"], e["lo"], e["hi"]) for e in events if e["type"] == "search_iter"] == \
+           [(e["iteration"], e["working_months"], e["lo"], e["hi"]) for e in g["events"] if e["type"] == "search_iter"]
+    flat = [m for c in calls for m in c]
+    assert len(flat) == len(set(flat))                      # nothing evaluated twice
+    if slots == 1:
+        # without speculation only the verification window is batched
+        assert set(flat) == set(table)
+    else:
+        assert len(calls) < len(table)                      # fewer launches than probes

@@ -274,3 +274,65 @@ def test_search_at_50k_paths_per_probe_has_its_defining_properties():
     assert months - 1 in probed  # the verification sweep tests the month just before the answer
     full = sim._success_probability(sim.run_monte_carlo_simulations(months, 50_000)[0])
     assert full == prob
+
+
+@pytest.mark.parametrize("rng", ["philox", "numpy"])
+def test_probe_many_equals_one_launch_per_candidate(rng):
+    """mcr_probe_months_rng (candidates forked onto side streams) counts exactly what one count-only
+    launch per candidate counts — also with more candidates than side streams, duplicates of a month,
+    and on a non-default torch stream."""
+    import torch
+
+    from monte_carlo_retirement_amd import engine as E
+
+    g = load_golden("search.json")[0]
+    sim = RetirementMonteCarloSimulator(Config(**g["cfg"]), main_seed_override=g["seed"], rng=rng)
+    sim.use_search_seeds()
+    n = 4000
+    months = [0, 1, 7, 12, 13, 24, 36, 37, 59, 60, 61, 120, 12]   # 13 candidates > 8 side streams; 12 twice
+    params, r = sim._current_params(), sim._batch_rng(n)
+    expect = []
+    for m in months:
+        b = E.DeviceBatch(params, m, n, want="count")
+        b.launch(r, sim._stream_id, 0)
+        expect.append(b.counters.cpu().tolist())
+    got = E.probe_months(params, r, sim._stream_id, 0, n, months).cpu().tolist()
+    assert got == expect
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got2 = E.probe_months(params, r, sim._stream_id, 0, n, months)
+    side.synchronize()
+    assert got2.cpu().tolist() == expect
+    probs = sim._probe_many(months[:-1], n)
+    assert probs == {m: float(np.float64(e[0]) / np.float64(n) * 100.0) for m, e in zip(months[:-1], expect)}
+    assert E.probe_months(params, r, sim._stream_id, 0, n, []).shape == (0, 2)
+    with pytest.raises(RuntimeError, match="working_months must be >= 0"):
+        E.probe_months(params, r, sim._stream_id, 0, n, [5, -1])
+    # the failed call enqueued nothing: the next one is unaffected
+    assert E.probe_months(params, r, sim._stream_id, 0, n, months[:3]).cpu().tolist() == expect[:3]
+
+
+def test_batched_search_equals_one_probe_at_a_time():
+    """find_minimum_working_months with candidate batches (the verification window in one call; bracket and
+    bisection points evaluated ahead when they are free) returns exactly what strictly one launch per
+    probe returns."""
+    import json
+    import os
+
+    from conftest import REPO
+
+    with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
+        cfg = Config(**dict(json.load(fh), num_simulations_search=20_000, seed=99))
+    ea, eb, calls_a, calls_b = [], [], [], []
+    a = RetirementMonteCarloSimulator(cfg)
+    a._speculation_slots = lambda n: 4          # as under a 4-rank process group
+    many_a = a._probe_many
+    a._probe_many = lambda months, n: (calls_a.append(len(months)), many_a(months, n))[1]
+    ra = a.find_minimum_working_months(verbose=False, progress_callback=ea.append)
+    b = RetirementMonteCarloSimulator(cfg)
+    many_b = b._probe_many
+    b._probe_many = lambda months, n: {m: (calls_b.append(1), many_b([m], n))[1][m] for m in months}
+    rb = b.find_minimum_working_months(verbose=False, progress_callback=eb.append)
+    assert ra == rb and ea == eb
+    assert b._speculation_slots(20_000) == 1
+    assert max(calls_a) > 1 and len(calls_a) < len(calls_b) <= len(rb[2])   # fewer, wider calls

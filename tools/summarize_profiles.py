@@ -1,0 +1,88 @@
+"""Condense the output of tools/collect_profiles.sh into the files committed under profiles/<round>/:
+kernel_stats.csv (rocprofv3 --stats summary), pmc_summary.json (per-kernel PMC means + derived figures),
+bench_default.json, and profiles/pmc_traffic.json (the roofline.traffic figure bench.py reports).
+
+    python tools/summarize_profiles.py gpurun_out/<dir> profiles/<round_dir>
+
+FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per the gfx950 correction in
+/opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+PATHS_COUNT, MONTHS_COUNT = 1_000_000, 833            # bench.py workload (configs[1])
+PATHS_FULL, T_FULL, RY_FULL = 4_000_000, 48, 40        # bench.py hbm_kernels block (configs[2] shape)
+
+
+def label(kernel_name: str):
+    k = kernel_name
+    if "path_kernel<0" in k:
+        return "K1 path_kernel<0,...> (count-only, 1e6 paths x 833 months)"
+    if "path_kernel<2" in k:
+        return "K1 path_kernel<2,...> (full output, 4e6 paths x 555 months)"
+    for tag, name in (("rq_hist", "K3 rq_hist_kernel"), ("rq_cand", "K3 rq_cand_hist_kernel"), ("rq_scan", "K3 rq_scan_kernel")):
+        if tag in k:
+            return name
+    if "hist_kernel" in k or "minmax" in k:
+        return "K2 hist/minmax"
+    return None
+
+
+def main(src: str, dst: str) -> None:
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in ("pmc_sq", "pmc_mix", "pmc_fetch", "pmc_write"):
+        f = glob.glob(os.path.join(src, d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        for r in csv.DictReader(open(f)):
+            short = label(r["Kernel_Name"])
+            if short:
+                per_kernel[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()}
+            for k, cs in per_kernel.items()}
+    k0 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<0"))
+    k2 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<2"))
+    k3 = summ["K3 rq_hist_kernel"]
+    m = lambda k, c: k[c]["mean_per_launch"]
+    wave_months = (PATHS_COUNT / 64) * MONTHS_COUNT
+    stat_rows = list(csv.DictReader(open(stats)))
+    k1_ms = next(float(r["AverageNs"]) for r in stat_rows if "path_kernel<0" in r["Name"]) / 1e6
+    alg_full = PATHS_FULL * (8 * (2 * T_FULL + RY_FULL + 6) + 1)
+    derived = {
+        "K1_count_avg_ms_from_kernel_stats": k1_ms,
+        "K1_count_valu_wave_insts_per_path_month": m(k0, "SQ_INSTS_VALU") / wave_months,
+        "K1_count_salu_wave_insts_per_path_month": m(k0, "SQ_INSTS_SALU") / wave_months,
+        "K1_count_fp64_add_mul_fma_per_path_month":
+            (m(k0, "SQ_INSTS_VALU_ADD_F64") + m(k0, "SQ_INSTS_VALU_MUL_F64") + m(k0, "SQ_INSTS_VALU_FMA_F64")) / wave_months,
+        "K1_count_trans_f64_per_path_month": m(k0, "SQ_INSTS_VALU_TRANS_F64") / wave_months,
+        "K1_count_lds_insts_per_path_month": m(k0, "SQ_INSTS_LDS") / wave_months,
+        "K1_count_hbm_bytes_per_launch": (2 * m(k0, "FETCH_SIZE") + m(k0, "WRITE_SIZE")) * 1024,
+        "shader_clock_GHz_K1_count": m(k0, "GRBM_GUI_ACTIVE") / 8 / (k1_ms * 1e-3) / 1e9,
+        "K1_full_WRITE_SIZE_bytes_per_launch": m(k2, "WRITE_SIZE") * 1024,
+        "K1_full_algorithmic_write_bytes": alg_full,
+        "K1_full_write_efficiency_algorithmic_over_measured": alg_full / (m(k2, "WRITE_SIZE") * 1024),
+        "K3_hist_FETCH_SIZE_x2_bytes_per_launch_mean": 2 * m(k3, "FETCH_SIZE") * 1024,
+    }
+    json.dump({
+        "command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "
+                   "(separate passes: SQ, SQ instruction mix, FETCH_SIZE, WRITE_SIZE; tools/collect_profiles.sh)",
+        "note": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM)",
+        "kernels": summ, "derived": derived,
+    }, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+    json.dump({
+        "round": 1, "source": os.path.join(dst, "pmc_summary.json"),
+        "path_kernel_count_only_bytes_per_launch": derived["K1_count_hbm_bytes_per_launch"],
+        "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of 1e6 paths; the algorithmic traffic of the count-only kernel "
+                "is ~3907 workgroups x (2 + <=102) 8-byte atomics",
+    }, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(derived, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
