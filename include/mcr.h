@@ -276,6 +276,20 @@ int mcr_histogram_success(const double* values, const uint8_t* success, int64_t 
                           const double* minmax, int32_t n_bins, uint64_t* bins,
                           int device, void* hip_stream);
 
+/*
+ * Rows for the summary statistics of the response document (backend/server.py:446-458 and
+ * median_first_year_withdrawal_rate, backend/simulation.py:78-96), laid out for mcr_row_quantiles
+ * (which skips NaN exactly as pandas' median/quantile do):
+ *   row 0 = Start Balance                      row 1 = Final Balance
+ *   row 2 = Final Balance where Success, else NaN
+ *   row 3 = First Year Real Gross Withdrawal / Start Balance * 100 where Start Balance > 1e-6, else NaN
+ * Inputs: DEVICE [n].  rows: DEVICE [4][row_stride] (row_stride >= n).
+ */
+#define MCR_N_STAT_ROWS 4
+int mcr_summary_stat_rows(const double* start_balance, const double* final_balance,
+                          const double* first_year_real_gross, const uint8_t* success, int64_t n,
+                          double* rows, int64_t row_stride, int device, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

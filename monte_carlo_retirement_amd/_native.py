@@ -15,6 +15,7 @@ from typing import Optional
 MCR_ABI_VERSION = 2
 MCR_MAX_STREAMS = 16
 MCR_N_COUNTERS = 2
+MCR_N_STAT_ROWS = 4
 MCR_CTR_SUCCESS = 0
 MCR_CTR_PATHS = 1
 MCR_STREAM_SEARCH = 0
@@ -181,6 +182,7 @@ ABI_SYMBOLS = (
     "mcr_row_quantiles_scan",
     "mcr_minmax_success",
     "mcr_histogram_success",
+    "mcr_summary_stat_rows",
 )
 
 _LIB_NAME = "libmcr_hip.so"
@@ -269,6 +271,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.mcr_histogram_success.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
         C.c_int, C.c_void_p,
+    ]
+    lib.mcr_summary_stat_rows.restype = C.c_int
+    lib.mcr_summary_stat_rows.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
     ]
 
 

@@ -138,3 +138,19 @@ def success_histogram(values, success, n_bins: int = 100, value_range: Optional[
     if lo == hi:
         lo, hi = lo - 0.5, hi + 0.5
     return bins.cpu().numpy(), np.linspace(lo, hi, n_bins + 1)
+
+
+def summary_stat_rows(batch, n: int):
+    """Device rows ``[4, stride]`` for the response document's summary statistics (start balance | final
+    balance | final balance of successful paths | first-year real withdrawal rate in %, NaN = outside the
+    cohort), ready for :func:`row_quantiles` — see ``mcr_summary_stat_rows`` (include/mcr.h)."""
+    import torch
+
+    s = batch.summary
+    stride = (int(n) + 63) // 64 * 64
+    rows = torch.empty((N.MCR_N_STAT_ROWS, stride), dtype=torch.float64, device=batch.success.device)
+    stream = C.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
+    N.check(N.load_library().mcr_summary_stat_rows(
+        s["start_balance"].data_ptr(), s["final_balance"].data_ptr(), s["first_year_real_gross_withdrawal"].data_ptr(),
+        batch.success.data_ptr(), int(n), rows.data_ptr(), stride, rows.device.index or 0, stream), "mcr_summary_stat_rows")
+    return rows

@@ -390,6 +390,22 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
     }
 }
 
+// Summary-statistic rows of the response document (server.py:446-458; simulation.py:78-96).  HBM-bound:
+// 25 B read + 32 B written per path.  Plain IEEE division and multiply: the rate is (w / start) * 100.0,
+// rounded twice like the pandas expression.
+__global__ __launch_bounds__(256) void stat_rows_kernel(const double* __restrict__ start, const double* __restrict__ fin,
+                                                       const double* __restrict__ fy_real, const uint8_t* __restrict__ ok,
+                                                       int64_t n, double* __restrict__ rows, int64_t stride) {
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double s = start[i], f = fin[i];
+        rows[i] = s;
+        rows[stride + i] = f;
+        rows[2 * stride + i] = ok[i] ? f : nan;
+        rows[3 * stride + i] = (s > 1e-6) ? (fy_real[i] / s) * 100.0 : nan;
+    }
+}
+
 // np.histogram(x, bins=n_bins) over [lo, hi] (numpy/lib/_histograms_impl.py, uniform-bin fast path):
 // index = int((x - lo) / (hi - lo) * n_bins), the right edge belongs to the last bin, then a
 // +-1 correction against the linspace edges.
@@ -588,6 +604,22 @@ int mcr_histogram_success(const double* values, const uint8_t* success, int64_t 
                        (hipStream_t)hip_stream, values, success, n, minmax, (int)n_bins, (unsigned long long*)bins);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hist_kernel");
+    return MCR_OK;
+}
+
+int mcr_summary_stat_rows(const double* start_balance, const double* final_balance, const double* first_year_real_gross,
+                          const uint8_t* success, int64_t n, double* rows, int64_t row_stride, int device, void* hip_stream) {
+    int rc = use_device(device);
+    if (rc != MCR_OK) return rc;
+    if (!start_balance || !final_balance || !first_year_real_gross || !success || !rows || n < 0 || row_stride < n) {
+        set_error("bad arguments");
+        return MCR_ERR_INVALID_ARG;
+    }
+    if (n == 0) return MCR_OK;
+    hipLaunchKernelGGL(stat_rows_kernel, dim3(grid_for(n, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)hip_stream,
+                       start_balance, final_balance, first_year_real_gross, success, n, rows, row_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "stat_rows_kernel");
     return MCR_OK;
 }
 

@@ -529,6 +529,65 @@ def gen_search():
     return out
 
 
+def gen_server_stream():
+    """(f)-3: the reference's own server flows, driven through FastAPI's TestClient with the simulator class
+    swapped for a subclass that consumes the engine's shocks: POST /api/simulate/stream (SSE events incl.
+    the final `result` payload, server.py:322-413) and POST /api/simulate (server.py:301-319), plus the
+    7-tuple the final run_monte_carlo_simulations returned (the input of _build_result, server.py:423-434)."""
+    import server as ref_server
+    from fastapi.testclient import TestClient
+
+    captured = {}
+
+    class InjectedSim(ref_sim.RetirementMonteCarloSimulator):
+        def __init__(self, params_model, main_seed_override=None):
+            super().__init__(params_model, main_seed_override)
+            inject_engine_shocks(self, self.main_seed)
+
+        def run_monte_carlo_simulations(self, working_months, num_simulations):
+            t = super().run_monte_carlo_simulations(working_months, num_simulations)
+            if self._stream_name == "final":
+                captured["tuple"] = t
+                captured["args"] = (int(working_months), int(num_simulations))
+            return t
+
+    ref_server.RetirementMonteCarloSimulator = InjectedSim
+    client = TestClient(ref_server.app)
+    failing = [t for t in scenario_table() if t[0] == "FAILING_wm24"][0][1]
+    cases = [
+        ("jorge_search_then_final", dict(load_json("jorge.json"), num_processes=1, seed=12345, num_simulations_search=100,
+                                         num_simulations_main=300), None),
+        ("failing_override_wm24", dict(failing, num_processes=1, seed=99, num_simulations_main=200), 24),
+        ("unreachable_target", base_test_config(initial_balance=1_000.0, monthly_expenses=50_000.0, target_probability=99.0,
+                                                num_simulations_search=20, num_simulations_main=20), None),
+    ]
+    out = []
+    for name, cfgd, override in cases:
+        body = {"config": cfgd}
+        if override is not None:
+            body["working_months_override"] = override
+        captured.clear()
+        r = client.post("/api/simulate/stream", json=body)
+        assert r.status_code == 200, r.text
+        events = [json.loads(line[len("data: "):]) for line in r.text.split("\n") if line.startswith("data: ")]
+        t = captured.get("tuple")
+        entry = {"name": name, "cfg": cfgd, "working_months_override": override, "events": events}
+        if t is not None:
+            entry["final_args"] = list(captured["args"])
+            entry["final_tuple"] = {
+                "summary": {k: [float(x) if k != "Success" else bool(x) for x in t[0][k].tolist()] for k in SUMMARY_KEYS},
+                "trajectory_percentiles": frame_to_jsonable(t[1]), "sample_trajectories": t[2],
+                "wr_percentiles": frame_to_jsonable(t[3]), "real_trajectory_percentiles": frame_to_jsonable(t[4]),
+                "sample_real_trajectories": t[5], "wr_observation_counts": t[6],
+            }
+        r2 = client.post("/api/simulate", json=body)
+        entry["simulate_status"] = r2.status_code
+        entry["simulate_body"] = r2.json()
+        out.append(entry)
+        print(f"  server {name}: {len(events)} events, last={events[-1]['type']}, /api/simulate -> {r2.status_code}", flush=True)
+    return out
+
+
 def gen_10k(outdir):
     """The metric's 10k-path config: config.json, wm=233, final stream, seed 12345, engine shocks."""
     cfgd = dict(load_json("config.json"), num_processes=1)
@@ -612,6 +671,8 @@ def main():
         dump("aggregation.json", gen_aggregation())
     if want("search"):
         dump("search.json", gen_search())
+    if want("server"):
+        dump("server_stream.json", gen_server_stream())
     if want("native_batch"):
         dump("numpy_native_batch.json", gen_numpy_native_batch())
     if want("native_stats"):

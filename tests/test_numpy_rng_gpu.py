@@ -114,7 +114,10 @@ def test_cli_flow_reproduces_the_references_surveyed_numbers():
         return json.loads(out.stdout.strip().splitlines()[-1])
 
     j = run("jorge.json")
-    assert (j["required_working_months"], j["search_probes"], j["success_probability"]) == (75, 33, 98.5)
+    assert (j["summary"]["required_working_months"], j["search_probes"], j["summary"]["success_probability"]) == (75, 33, 98.5)
     c = run("config.json")
-    assert (c["required_working_months"], c["search_probes"], c["success_probability"]) == (233, 29, 97.9)
-    assert c["trajectory_years"] == 71 and c["sample_paths"] == 5
+    assert (c["summary"]["required_working_months"], c["search_probes"], c["summary"]["success_probability"]) == (233, 29, 97.9)
+    assert c["trajectory_points"] == 71 and c["sample_paths"] == 5
+    # the device-aggregated document reports the same summary block
+    k = run("config.json", "--compact")
+    assert k["summary"] == c["summary"] and k["search_probes"] == 29 and k["document_bytes"] < c["document_bytes"]
