@@ -176,6 +176,7 @@ ABI_SYMBOLS = (
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
+    "mcr_row_quantiles_last_fallback_rows",
     "mcr_row_quantiles_reduce_block",
     "mcr_row_quantiles_begin",
     "mcr_row_quantiles_hist",
@@ -272,6 +273,8 @@ def _declare(lib: C.CDLL) -> None:
         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
         C.c_int, C.c_void_p,
     ]
+    lib.mcr_row_quantiles_last_fallback_rows.restype = C.c_int
+    lib.mcr_row_quantiles_last_fallback_rows.argtypes = []
     lib.mcr_summary_stat_rows.restype = C.c_int
     lib.mcr_summary_stat_rows.argtypes = [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,

@@ -76,6 +76,12 @@ def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0, reduce_cou
     return out.cpu().numpy(), counts.cpu().numpy()
 
 
+def last_fallback_rows() -> int:
+    """Diagnostics for the calling thread's last :func:`row_quantiles`: -1 = the radix route was taken, else how
+    many rows of the bracketed route needed the full radix passes."""
+    return int(N.load_library().mcr_row_quantiles_last_fallback_rows())
+
+
 def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int):
     import torch
 

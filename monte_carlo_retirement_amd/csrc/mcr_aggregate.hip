@@ -10,10 +10,19 @@
 //     _QuantileMethods['linear'] / _get_indexes / _lerp), which is what DataFrame.quantile(q, axis=1)
 //     evaluates.  NaNs are skipped (the WR rows carry NaN by design, simulation.py:851,934-935).
 //     HBM-bound: each pass streams the [rows][n] slab once, 8 B/element, coalesced.
+//     Large rows avoid most of those passes (mcr_row_quantiles, single GPU): the same select runs first
+//     on a SAMPLE (the first n/32 entries) to get, per quantile, a bracket of keys that contains the
+//     wanted order statistics with overwhelming probability; ONE pass over the slab then counts the keys
+//     below / inside every bracket and compacts the few percent inside; the select finishes on those
+//     candidates with ranks shifted by the counts.  Exactness never depends on the sample: a row whose
+//     counts show a target outside its bracket (or whose candidates overflow: giant ties) simply takes
+//     the full radix passes.  Traffic: ~1.5 reads of the slab instead of 4.
 // K2  cohort min/max + np.histogram-style equal-width bins over the successful cohort.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/mcr.h"
 #include "mcr_host.h"
@@ -35,6 +44,27 @@ struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
     unsigned int cand_count;             // keys appended to the (rank-local) candidate buffer in pass 3
     unsigned int const_row;              // 1: every non-NaN entry of the row is the same value (done after pass 0)
     unsigned long long kmin, kmax;       // min / max key of the row (pass 0; only when the shortcut is enabled)
+    unsigned int clamp_lo, clamp_hi;     // sample mode: bit j = bracket end of quantile j runs off the sample's range
+};
+
+// What the targets of a select are (rq_scan_kernel):
+constexpr int kRqQuantiles = 0;  // order statistics around (n-1)*q, interpolated and written to `out` (the plain select)
+constexpr int kRqSample = 1;     // bracket ranks around (m-1)*q in a sample of m entries; selected values stay in RqRow
+constexpr int kRqExplicit = 2;   // ranks preset by rq_resolve_kernel (candidate select); selected values stay in RqRow
+constexpr unsigned long long kRqKeyPosInf = 0xFFF0000000000000ull;   // key_of(+inf): the largest non-NaN key
+constexpr double kRqBracketSigmas = 5.0;   // half-width of a bracket in binomial standard deviations of the sample rank
+
+// Disjoint, ascending key intervals of one row (from its sample) and what the bracket pass counted for them.
+struct RqBracket {
+    unsigned long long lo[kRqMaxQ], hi[kRqMaxQ];   // closed key intervals [lo, hi]
+    // bracket pass: # non-NaN keys by position among the sorted bounds lo0 <= hi0 < lo1 <= hi1 < ...:
+    // position 2b+1 = inside interval b, position 2b = in the gap below it (2*n_intervals = above the last)
+    unsigned long long pos_count[2 * kRqMaxQ + 1];
+    unsigned long long n_nan;
+    int interval_of_q[kRqMaxQ];
+    int n_intervals;
+    unsigned int cand_count;                       // values appended to the row's candidate buffer
+    unsigned int fallback;                         // 1: the row takes the full radix passes
 };
 // Scratch layout: RqRow[n_rows] | hist u32[n_rows][kRqMaxT][256] | aux u32[n_rows][2] | cand u64[n_rows][cap].
 // hist|aux is ONE dense block of 32-bit counters: a multi-GPU caller sums it across ranks after every
@@ -79,16 +109,23 @@ template <bool FIRST, bool COMPACT>
 __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restrict__ rows, int64_t row_stride,
                                                           int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                           unsigned int* aux, unsigned long long* cand,
-                                                          unsigned int cand_cap, int only_overflowed, int track_minmax) {
+                                                          unsigned int cand_cap, int only_overflowed, int track_minmax,
+                                                          const unsigned int* __restrict__ row_n,
+                                                          const unsigned int* __restrict__ row_list) {
     extern __shared__ __align__(16) unsigned int lh[];  // [max groups of this call][256], sized by the host
     __shared__ unsigned long long lpref[kRqMaxT];
     __shared__ unsigned int lnan;
     constexpr int kStage = 1024;  // candidate keys staged per workgroup before ONE global slot reservation
     __shared__ unsigned long long stage[COMPACT ? kStage : 1];
     __shared__ unsigned int stage_n, stage_base;
-    const int row = blockIdx.y;
+    const int row = row_list ? (int)row_list[blockIdx.y] : (int)blockIdx.y;   // a call may concern a list of rows only
     if (only_overflowed && !aux[2 * row + 1]) return;  // slow path only for rows whose candidates overflowed
     if (!FIRST && st[row].const_row) return;           // all-equal row: finished after pass 0
+    if (row_n) {                                       // ragged rows (candidate buffers): this row's own length
+        const int64_t mine = (int64_t)row_n[row];
+        n = mine < n ? mine : n;
+        if (n == 0) return;
+    }
     const int G = FIRST ? 1 : st[row].n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
@@ -198,12 +235,13 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
 // are a few thousand keys, L2-resident).  Rows whose candidates overflowed are left to the slow path.
 __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow* st, unsigned int* hist,
                                                                const unsigned int* aux,
-                                                               const unsigned long long* cand, unsigned int cand_cap) {
+                                                               const unsigned long long* cand, unsigned int cand_cap,
+                                                               const unsigned int* __restrict__ row_list) {
     extern __shared__ __align__(16) unsigned int lh[];
     __shared__ unsigned long long lpref[kRqMaxT];
-    const int row = blockIdx.y;
+    const int row = row_list ? (int)row_list[blockIdx.y] : (int)blockIdx.y;
     RqRow& S = st[row];
-    if (aux[2 * row + 1] || S.const_row) return;
+    if (aux[2 * row + 1] || S.const_row || S.n_targets == 0) return;
     const int G = S.n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if (threadIdx.x < G) lpref[threadIdx.x] = S.prefix[threadIdx.x];
@@ -233,47 +271,77 @@ __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow*
 // interpolate (NumPy `linear`) and write the quantiles.
 __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                     const RqArgs args, double* out, unsigned long long* counts,
-                                                    unsigned int* aux) {
-    __shared__ unsigned long long new_prefix[kRqMaxT];
+                                                    unsigned int* aux, int mode,
+                                                    const unsigned int* __restrict__ row_list) {
+    __shared__ unsigned long long new_prefix[kRqMaxT], grp_prefix[kRqMaxT];
+    __shared__ int grp_of[kRqMaxT], n_grp;
     extern __shared__ __align__(16) unsigned int sh[];  // this row's histograms, [n_groups][256]
-    const int row = blockIdx.x;
-    RqRow& S = st[row];
+    const int row = row_list ? (int)row_list[blockIdx.x] : (int)blockIdx.x;
+    // the row's state is worked on in LDS (one coalesced load, one store): the serial parts below would otherwise
+    // be chains of dependent global accesses
+    __shared__ RqRow S;
+    static_assert(sizeof(RqRow) % sizeof(unsigned int) == 0, "RqRow is copied word by word");
+    constexpr int kRowWords = (int)(sizeof(RqRow) / sizeof(unsigned int));
+    unsigned int* g_state = reinterpret_cast<unsigned int*>(&st[row]);
+    unsigned int* l_state = reinterpret_cast<unsigned int*>(&S);
     unsigned int* gh = hist + (size_t)row * kRqMaxT * 256;
     const int t = threadIdx.x;
+    for (int k = t; k < kRowWords; k += 64) l_state[k] = g_state[k];
     {
-        const int ng = pass == 0 ? 1 : S.n_groups;
+        // (groups beyond the row's current count hold zeros: reading up to the call's maximum needs no dependent load)
+        const int ng = pass == 0 ? 1 : 2 * args.n_q;
         for (int k = t; k < ng * 256; k += 64) sh[k] = gh[k];
     }
-    if (pass == 0 && t == 0) {
+    __syncthreads();
+    auto store_state = [&]() {
+        __syncthreads();
+        for (int k = t; k < kRowWords; k += 64) g_state[k] = l_state[k];
+    };
+    if (pass == 0 && t == 0 && mode != kRqExplicit) {
         const unsigned long long m = (unsigned long long)n - (unsigned long long)aux[2 * row];
         S.n_valid = m;
         if (counts) counts[row] = m;
         int nt = 0;
+        unsigned int clamp_lo = 0u, clamp_hi = 0u;
         if (m > 0) {
             for (int j = 0; j < args.n_q; ++j) {
                 // _QuantileMethods['linear'].get_virtual_index = (n - 1) * quantiles
                 const double q = args.q[j];
                 const double vi = (double)(m - 1) * q;
-                double prev = floor(vi), next = prev + 1.0;          // _get_indexes
-                if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
-                if (vi < 0.0) { prev = 0.0; next = 0.0; }
-                S.gamma[j] = vi - floor(vi);                          // _get_gamma (linear: unchanged)
-                S.rank[nt] = (unsigned long long)prev; S.group_of[nt] = 0; ++nt;
-                S.rank[nt] = (unsigned long long)next; S.group_of[nt] = 0; ++nt;
+                if (mode == kRqQuantiles) {
+                    double prev = floor(vi), next = prev + 1.0;          // _get_indexes
+                    if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
+                    if (vi < 0.0) { prev = 0.0; next = 0.0; }
+                    S.gamma[j] = vi - floor(vi);                          // _get_gamma (linear: unchanged)
+                    S.rank[nt] = (unsigned long long)prev; S.group_of[nt] = 0; ++nt;
+                    S.rank[nt] = (unsigned long long)next; S.group_of[nt] = 0; ++nt;
+                } else {
+                    // sample of m entries: the order statistics of the whole row around quantile q lie, with
+                    // overwhelming probability, between the sample's order statistics this far from (m-1)*q
+                    const double d = ceil(kRqBracketSigmas * sqrt((double)m * q * (1.0 - q))) + 2.0;
+                    double lo = floor(vi) - d, hi = floor(vi) + 1.0 + d;
+                    if (lo < 0.0) { lo = 0.0; clamp_lo |= 1u << j; }                      // bracket open below
+                    if (hi > (double)(m - 1)) { hi = (double)(m - 1); clamp_hi |= 1u << j; }  // bracket open above
+                    S.rank[nt] = (unsigned long long)lo; S.group_of[nt] = 0; ++nt;
+                    S.rank[nt] = (unsigned long long)hi; S.group_of[nt] = 0; ++nt;
+                }
             }
         }
         S.n_targets = nt;
         S.n_groups = 1;
         S.prefix[0] = 0ull;
+        S.clamp_lo = clamp_lo;
+        S.clamp_hi = clamp_hi;
         // all non-NaN entries equal (e.g. the t = 0 rows: every path starts from the same balance): every order
         // statistic is that value — finish now; later passes skip the row (only when min/max were tracked)
-        S.const_row = (m > 0 && S.kmin == S.kmax) ? 1u : 0u;
+        S.const_row = (mode == kRqQuantiles && m > 0 && S.kmin == S.kmax) ? 1u : 0u;
     }
     __syncthreads();
     if (S.const_row) {
         if (pass == 0) {
             for (int k = t; k < 256; k += 64) gh[k] = 0u;
             if (t < args.n_q) out[(size_t)row * args.n_q + t] = value_of(S.kmin);  // lerp(a, a, g) = a
+            store_state();
         }
         return;
     }
@@ -294,23 +362,27 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
     __syncthreads();
     const int old_groups = S.n_groups;
     __syncthreads();
-    if (t == 0) {  // regroup: targets that still share a prefix share a histogram
+    if (t == 0) {  // regroup: targets that still share a prefix share a histogram (worked out in LDS, stored below)
         int ng = 0;
         for (int a = 0; a < nt; ++a) {
             int g = -1;
             for (int b = 0; b < ng; ++b)
-                if (S.prefix[b] == new_prefix[a]) { g = b; break; }
-            if (g < 0) { g = ng++; S.prefix[g] = new_prefix[a]; }
-            S.group_of[a] = g;
+                if (grp_prefix[b] == new_prefix[a]) { g = b; break; }
+            if (g < 0) { g = ng++; grp_prefix[g] = new_prefix[a]; }
+            grp_of[a] = g;
         }
-        S.n_groups = ng > 0 ? ng : 1;
+        n_grp = ng > 0 ? ng : 1;
     }
+    __syncthreads();
+    if (t < nt) S.group_of[t] = grp_of[t];
+    if (t < n_grp && nt > 0) S.prefix[t] = grp_prefix[t];
+    if (t == 0) S.n_groups = n_grp;
     for (int k = t; k < old_groups * 256; k += 64) gh[k] = 0u;  // ready for the next pass / call
     __syncthreads();
     if (pass == 7) {
         if (t < nt) S.value[t] = value_of(new_prefix[t]);
         __syncthreads();
-        if (t < args.n_q) {
+        if (mode == kRqQuantiles && t < args.n_q) {
             double r;
             if (S.n_valid == 0) {
                 r = __longlong_as_double(0x7ff8000000000000LL);  // all-NaN row -> NaN (pandas na_value)
@@ -323,6 +395,7 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
             out[(size_t)row * args.n_q + t] = r;
         }
     }
+    store_state();
 }
 
 // after the compaction pass: did this rank's candidate buffer overflow for the row?
@@ -341,6 +414,275 @@ __global__ void rq_init_kernel(RqRow* st, unsigned int* hist, int n_rows) {
         st[r].cand_count = 0u; st[r].const_row = 0u;
         st[r].kmin = ~0ull; st[r].kmax = 0ull;  // kmin > kmax: "not tracked" (never equal)
     }
+}
+
+// ---- K3, bracketed single pass -------------------------------------------------------------------
+// After the sample select (kRqSample): turn the 2 bracket keys per quantile into disjoint ascending intervals.
+__global__ void rq_bracket_prep_kernel(const RqRow* st, RqBracket* br, int n_q, int n_rows, unsigned int* fb_count) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row == 0) *fb_count = 0u;
+    if (row >= n_rows) return;
+    const RqRow& S = st[row];
+    RqBracket& B = br[row];
+    B.n_nan = 0ull; B.cand_count = 0u; B.fallback = 0u; B.n_intervals = 0;
+    for (int b = 0; b < kRqMaxQ; ++b) { B.lo[b] = ~0ull; B.hi[b] = 0ull; B.interval_of_q[b] = 0; }
+    for (int k = 0; k <= 2 * kRqMaxQ; ++k) B.pos_count[k] = 0ull;
+    if (S.n_targets != 2 * n_q) { B.fallback = 1u; return; }   // the sample had no non-NaN entry
+    unsigned long long lo[kRqMaxQ], hi[kRqMaxQ];
+    int order[kRqMaxQ];
+    for (int j = 0; j < n_q; ++j) {
+        // open ends: the whole range of non-NaN keys.  The ends are exact order statistics of the sample, so a
+        // bracket that sits inside one giant tie comes out as a ONE-KEY interval (lo == hi), which needs no candidates.
+        lo[j] = ((S.clamp_lo >> j) & 1u) ? 0ull : key_of(S.value[2 * j]);
+        hi[j] = ((S.clamp_hi >> j) & 1u) ? kRqKeyPosInf : key_of(S.value[2 * j + 1]);
+        int k = j;
+        while (k > 0 && lo[order[k - 1]] > lo[j]) { order[k] = order[k - 1]; --k; }   // insertion sort by lo
+        order[k] = j;
+    }
+    int nb = 0;
+    for (int i = 0; i < n_q; ++i) {
+        const int j = order[i];
+        if (nb > 0 && lo[j] <= B.hi[nb - 1]) {
+            if (hi[j] > B.hi[nb - 1]) B.hi[nb - 1] = hi[j];      // overlapping brackets share an interval
+        } else {
+            B.lo[nb] = lo[j]; B.hi[nb] = hi[j]; ++nb;
+        }
+        B.interval_of_q[j] = nb - 1;
+    }
+    B.n_intervals = nb;
+}
+
+// THE pass over the slab.  Every non-NaN key is located among the row's sorted interval bounds by a branch-free
+// binary search (P-entry table in LDS: bound 2b = lo[b], bound 2b+1 = hi[b]+1, padded with ~0; position = number of
+// bounds <= key), counted in a per-thread LDS histogram laid out [position][thread] (conflict-free, plain
+// read-modify-write: no atomics), and — when its position is odd, i.e. it lies inside an interval that is a real
+// range — appended to the row's candidate buffer (staged per wave in LDS: one global reservation and a coalesced
+// copy per ~256 candidates, no workgroup barrier in the loop).
+// 8 B/element read, a few % written.
+template <int P>
+__global__ __launch_bounds__(kRqBlock) void rq_bracket_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
+                                                             RqBracket* br, double* cand, unsigned int cand_cap) {
+    constexpr int kWaveStage = 256;                      // candidates a wave collects in LDS before it appends them
+    __shared__ double stage[(kRqBlock / 64) * kWaveStage];
+    __shared__ unsigned long long bound[P];
+    __shared__ unsigned int poshist[P * kRqBlock];
+    __shared__ unsigned int nan_n;
+    const int row = blockIdx.y;
+    RqBracket& B = br[row];
+    const int nb = B.n_intervals;
+    if (B.fallback || 2 * nb >= P) return;             // (the host picks P > 2 * n_q >= 2 * nb)
+    if (threadIdx.x < P) {
+        const int b = threadIdx.x >> 1;
+        bound[threadIdx.x] = b < nb ? ((threadIdx.x & 1) ? B.hi[b] + 1ull : B.lo[b]) : ~0ull;   // hi <= key(+inf): no wrap
+    }
+    for (int k = threadIdx.x; k < P * kRqBlock; k += kRqBlock) poshist[k] = 0u;
+    if (threadIdx.x == 0) nan_n = 0u;
+    unsigned int keep = 0u;                            // bit b: interval b is a real range (lo < hi): members are candidates
+    for (int b = 0; b < nb; ++b) keep |= (B.lo[b] < B.hi[b]) ? (1u << b) : 0u;
+    keep = (unsigned int)__builtin_amdgcn_readfirstlane((int)keep);
+    __syncthreads();
+    const double* r = rows + (int64_t)row * row_stride;
+    double* crow = cand + (size_t)row * cand_cap;
+    const int lane = threadIdx.x & 63;
+    unsigned int my_nan = 0u;
+    double* wstage = stage + (threadIdx.x >> 6) * kWaveStage;   // this wave's stage; `filled` is wave-uniform
+    unsigned int filled = 0u;
+    // append the wave's staged candidates to the row's buffer: one global reservation, coalesced copy
+    auto flush = [&]() {
+        if (filled == 0u) return;
+        unsigned int base = 0u;
+        if (lane == 0) base = atomicAdd(&B.cand_count, filled);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        for (unsigned int i = lane; i < filled; i += 64u)
+            if (base + i < cand_cap) crow[base + i] = wstage[i];
+        filled = 0u;
+    };
+
+    // K elements per lane at a time: first all K binary searches (independent LDS chains the scheduler can overlap),
+    // then ONE wave scan + ONE stage reservation for the candidates among the wave's 64 * K elements.
+    auto consume = [&](auto kc, const double* xs, const bool* oks) {
+        constexpr int K = decltype(kc)::value;
+        bool ins[K], valid[K];
+        unsigned long long key[K];
+        unsigned int pos[K];
+        unsigned int mine = 0u;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const double x = xs[u];
+            const bool isnan_x = x != x;
+            my_nan += (oks[u] && isnan_x) ? 1u : 0u;
+            valid[u] = oks[u] && !isnan_x;
+            key[u] = key_of(x);
+            pos[u] = 0u;
+        }
+        // level by level across the K elements: K independent LDS reads in flight per level, no branches
+#pragma unroll
+        for (int half = P / 2; half >= 1; half >>= 1) {
+#pragma unroll
+            for (int u = 0; u < K; ++u) pos[u] += (bound[pos[u] + half - 1] <= key[u]) ? (unsigned int)half : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            atomicAdd(&poshist[pos[u] * kRqBlock + threadIdx.x], valid[u] ? 1u : 0u);   // own slot: ds_add_u32, no conflicts
+            ins[u] = valid[u] && (pos[u] & 1u) && ((keep >> (pos[u] >> 1)) & 1u);
+            mine += ins[u] ? 1u : 0u;
+        }
+        if (__ballot(mine != 0u)) {           // wave-uniform
+            unsigned int scan = mine;         // inclusive scan of the per-lane candidate counts
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned int up = (unsigned int)__shfl_up((int)scan, off, 64);
+                scan += lane >= off ? up : 0u;
+            }
+            const unsigned int total = (unsigned int)__builtin_amdgcn_readlane((int)scan, 63);
+            if (total > (unsigned int)kWaveStage) {
+                // more than a stage of candidates in one batch (a wide interval): straight to the row's buffer
+                flush();
+                unsigned int base = 0u;
+                if (lane == 0) base = atomicAdd(&B.cand_count, total);
+                unsigned int slot = (unsigned int)__builtin_amdgcn_readfirstlane((int)base) + scan - mine;
+#pragma unroll
+                for (int u = 0; u < K; ++u)
+                    if (ins[u]) { if (slot < cand_cap) crow[slot] = xs[u]; ++slot; }
+            } else {
+                if (filled + total > (unsigned int)kWaveStage) flush();
+                unsigned int slot = filled + scan - mine;
+#pragma unroll
+                for (int u = 0; u < K; ++u)
+                    if (ins[u]) wstage[slot++] = xs[u];
+                filled += total;
+            }
+        }
+    };
+
+    const int64_t step = (int64_t)gridDim.x * kRqBlock;
+    const bool vec2 = ((row_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+    if (vec2) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t* r2 = reinterpret_cast<const d2_t*>(r);
+        const int64_t n_pairs = n / 2;
+        const int64_t trips = (n_pairs + step - 1) / step;
+        constexpr int kUnroll = 4;     // four 16-byte loads in flight per lane
+        for (int64_t t = 0; t < trips; t += kUnroll) {
+            d2_t v[kUnroll];
+            double xs[2 * kUnroll];
+            bool oks[2 * kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t i = (t + u) * step + (int64_t)blockIdx.x * kRqBlock + threadIdx.x;
+                oks[2 * u] = oks[2 * u + 1] = i < n_pairs;
+                v[u] = oks[2 * u] ? __builtin_nontemporal_load(&r2[i]) : d2_t{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) { xs[2 * u] = v[u].x; xs[2 * u + 1] = v[u].y; }
+            consume(std::integral_constant<int, 2 * kUnroll>{}, xs, oks);
+        }
+        if ((n & 1) && blockIdx.x == 0) {
+            const double x1 = r[n - 1];
+            const bool ok1 = threadIdx.x == 0;
+            consume(std::integral_constant<int, 1>{}, &x1, &ok1);
+        }
+    } else {
+        const int64_t trips = (n + step - 1) / step;
+        for (int64_t t = 0; t < trips; ++t) {
+            const int64_t i = t * step + (int64_t)blockIdx.x * kRqBlock + threadIdx.x;
+            const bool ok1 = i < n;
+            const double x1 = ok1 ? r[i] : 0.0;
+            consume(std::integral_constant<int, 1>{}, &x1, &ok1);
+        }
+    }
+    if (my_nan) atomicAdd(&nan_n, my_nan);
+    __syncthreads();
+    // fold the per-thread histograms: one wave per position at a time, one global atomic per position and workgroup
+    for (int p = threadIdx.x >> 6; p <= 2 * nb; p += kRqBlock / 64) {
+        unsigned int c = poshist[p * kRqBlock + lane] + poshist[p * kRqBlock + 64 + lane] +
+                         poshist[p * kRqBlock + 128 + lane] + poshist[p * kRqBlock + 192 + lane];
+        for (int off = 32; off > 0; off >>= 1) c += (unsigned int)__shfl_down((int)c, off, 64);
+        if (lane == 0 && c) atomicAdd(&B.pos_count[p], (unsigned long long)c);
+    }
+    if (threadIdx.x == 0 && nan_n) atomicAdd(&B.n_nan, (unsigned long long)nan_n);
+    flush();
+}
+
+// Per row, after the bracket pass: the true ranks (NumPy `linear`, as rq_scan_kernel computes them), checked
+// against the counts and shifted into ranks inside the candidate buffer.  A row any of whose targets lies outside
+// its interval, or whose candidates overflowed, is handed to the full radix passes.
+__global__ void rq_resolve_kernel(int64_t n, const RqArgs args, RqBracket* br, RqRow* st, unsigned int* row_n,
+                                  unsigned int* row_fallback, unsigned int* fb_list, unsigned int* fb_count,
+                                  unsigned long long* counts, unsigned int cand_cap, int n_rows) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    RqBracket& B = br[row];
+    RqRow& S = st[row];   // freshly initialised by rq_init_kernel
+    bool fb = B.fallback != 0u;
+    if (!fb) {
+        const unsigned long long m = (unsigned long long)n - B.n_nan;
+        S.n_valid = m;
+        if (counts) counts[row] = m;
+        unsigned long long below[kRqMaxQ], upto[kRqMaxQ], run = 0ull;   // # keys < lo[b], # keys <= hi[b]
+        for (int b = 0; b < B.n_intervals; ++b) {
+            run += B.pos_count[2 * b]; below[b] = run;
+            run += B.pos_count[2 * b + 1]; upto[b] = run;
+        }
+        unsigned long long inside_before[kRqMaxQ], total_inside = 0ull;
+        unsigned int known = 0u;   // bit j: quantile j sits in a one-key interval
+        for (int b = 0; b < B.n_intervals; ++b) {
+            inside_before[b] = total_inside;
+            if (B.lo[b] != B.hi[b]) total_inside += upto[b] - below[b];   // one-key intervals stored nothing
+        }
+        if (B.cand_count > cand_cap || total_inside != (unsigned long long)B.cand_count) fb = true;
+        int nt = 0;
+        if (!fb && m > 0) {
+            for (int j = 0; j < args.n_q; ++j) {
+                const double q = args.q[j];
+                const double vi = (double)(m - 1) * q;
+                double prev = floor(vi), next = prev + 1.0;
+                if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
+                if (vi < 0.0) { prev = 0.0; next = 0.0; }
+                S.gamma[j] = vi - floor(vi);
+                const int b = B.interval_of_q[j];
+                const bool tie = B.lo[b] == B.hi[b];   // one key: every member IS that value, none was stored
+                const unsigned long long r2[2] = {(unsigned long long)prev, (unsigned long long)next};
+                for (int e = 0; e < 2; ++e) {
+                    if (r2[e] < below[b] || r2[e] >= upto[b]) fb = true;           // outside the bracket: not provable here
+                    S.rank[nt] = tie ? 0ull : r2[e] - below[b] + inside_before[b];   // rank among the candidates
+                    S.group_of[nt] = 0;
+                    ++nt;
+                }
+                if (tie) known |= 1u << j;
+            }
+        }
+        S.n_targets = fb ? 0 : nt;
+        S.n_groups = 1;
+        S.prefix[0] = 0ull;
+        S.clamp_lo = known;        // (field reused: read by rq_finalize_kernel)
+    }
+    if (fb) { B.fallback = 1u; S.n_targets = 0; }
+    row_n[row] = fb ? 0u : B.cand_count;
+    row_fallback[row] = fb ? 1u : 0u;
+    if (fb) fb_list[atomicAdd(fb_count, 1u)] = (unsigned int)row;
+}
+
+// Interpolate the rows that were decided on their candidates (the fallback rows are written by the radix passes).
+__global__ void rq_finalize_kernel(const RqRow* st, const RqBracket* br, const unsigned int* row_fallback, int n_q, int n_rows,
+                                   double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * n_q) return;
+    const int row = i / n_q, t = i % n_q;
+    if (row_fallback[row]) return;
+    const RqRow& S = st[row];
+    double r;
+    if (S.n_valid == 0) {
+        r = __longlong_as_double(0x7ff8000000000000LL);
+    } else {
+        double a = S.value[2 * t], b = S.value[2 * t + 1];
+        const double g = S.gamma[t];
+        if ((S.clamp_lo >> t) & 1u) a = b = value_of(br[row].lo[br[row].interval_of_q[t]]);   // one-key interval
+        const double diff = b - a;                       // _lerp
+        r = a + diff * g;
+        if (g >= 0.5) r = b - diff * (1.0 - g);
+    }
+    out[(size_t)row * n_q + t] = r;
 }
 
 // ---- K2: successful-cohort min/max and equal-width histogram ------------------------------------
@@ -447,22 +789,47 @@ static int grid_for(int64_t n, int per_block, int cap) {
 
 static unsigned int rq_cand_cap(int64_t n) { return (unsigned int)(n / 64 + 4096); }
 
+static unsigned int rq_bracket_cand_cap(int64_t n) { return (unsigned int)((n / 8 + 4096) & ~(int64_t)1); }  // even: 16-byte rows
+
 struct RqLayout {
     RqRow* st;
     unsigned int* hist;
     unsigned int* aux;
     unsigned long long* cand;
     size_t reduce_offset, reduce_words;
+    // bracketed single pass (mcr_row_quantiles only)
+    RqBracket* br;
+    unsigned int* row_n;
+    unsigned int* row_fallback;
+    unsigned int* fb_list;      // rows that take the full radix passes, and how many
+    unsigned int* fb_count;
+    double* bcand;
+    size_t total_bytes;
 };
-static RqLayout rq_layout(void* scratch, int32_t n_rows) {
+static size_t rq_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+// Offsets first (also for a null base: mcr_row_quantiles_scratch_bytes), pointers after.  The stepwise
+// (multi-GPU) entry points pass n = 0: they only use st | hist | aux | cand, whose offsets do not depend on n.
+static RqLayout rq_layout(void* scratch, int32_t n_rows, int64_t n = 0) {
     RqLayout L;
+    L.reduce_offset = (size_t)n_rows * sizeof(RqRow);
+    L.reduce_words = (size_t)n_rows * kRqMaxT * 256 + (size_t)n_rows * 2;
+    const size_t off_aux = L.reduce_offset + (size_t)n_rows * kRqMaxT * 256 * sizeof(unsigned int);
+    const size_t off_cand = L.reduce_offset + ((L.reduce_words + 1) & ~(size_t)1) * sizeof(unsigned int);  // 8-byte aligned
+    const size_t off_br = rq_align16(off_cand + (size_t)n_rows * (size_t)rq_cand_cap(n) * sizeof(unsigned long long));
+    const size_t off_rn = rq_align16(off_br + (size_t)n_rows * sizeof(RqBracket));
+    const size_t off_bc = rq_align16(off_rn + ((size_t)n_rows * 3 + 1) * sizeof(unsigned int));
+    L.total_bytes = off_bc + (size_t)n_rows * (size_t)rq_bracket_cand_cap(n) * sizeof(double);
     char* base = (char*)scratch;
     L.st = (RqRow*)base;
-    L.reduce_offset = (size_t)n_rows * sizeof(RqRow);
     L.hist = (unsigned int*)(base + L.reduce_offset);
-    L.reduce_words = (size_t)n_rows * kRqMaxT * 256 + (size_t)n_rows * 2;
-    L.aux = L.hist + (size_t)n_rows * kRqMaxT * 256;
-    L.cand = (unsigned long long*)(L.hist + ((L.reduce_words + 1) & ~(size_t)1));  // 8-byte aligned
+    L.aux = (unsigned int*)(base + off_aux);
+    L.cand = (unsigned long long*)(base + off_cand);
+    L.br = (RqBracket*)(base + off_br);
+    L.row_n = (unsigned int*)(base + off_rn);
+    L.row_fallback = L.row_n + n_rows;
+    L.fb_list = L.row_fallback + n_rows;
+    L.fb_count = L.fb_list + n_rows;
+    L.bcand = (double*)(base + off_bc);
     return L;
 }
 
@@ -478,9 +845,7 @@ extern "C" {
 
 int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n) {
     if (n_rows <= 0 || n_q <= 0 || n_q > kRqMaxQ || n < 0 || n >= ((int64_t)1 << 32)) return 0;
-    const size_t words = (size_t)n_rows * kRqMaxT * 256 + (size_t)n_rows * 2;
-    return (int64_t)((size_t)n_rows * sizeof(RqRow) + ((words + 1) & ~(size_t)1) * sizeof(unsigned int) +
-                     (size_t)n_rows * (size_t)rq_cand_cap(n) * sizeof(unsigned long long));
+    return (int64_t)rq_layout(nullptr, n_rows, n).total_bytes;
 }
 
 int64_t mcr_row_quantiles_reduce_block(int32_t n_rows, int64_t* n_words) {
@@ -503,7 +868,9 @@ int mcr_row_quantiles_begin(void* scratch, int32_t n_rows, int device, void* hip
 }
 
 static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
-                        int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax);
+                        int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax,
+                        const unsigned int* row_n = nullptr, const unsigned int* row_list = nullptr, int n_list = 0,
+                        int slow_cap = 512);
 
 int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
                            int32_t pass, void* scratch, int device, void* hip_stream) {
@@ -512,7 +879,8 @@ int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_row
 }
 
 static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
-                        int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax) {
+                        int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax,
+                        const unsigned int* row_n, const unsigned int* row_list, int n_list, int slow_cap) {
     int rc = use_device(device);
     if (rc != MCR_OK) return rc;
     rc = rq_check(scratch, n_rows, n_local, n_q);
@@ -525,22 +893,23 @@ static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, 
     const int64_t n = n_local;
     if (n > 0) {
         // each workgroup streams >= 16 elements per lane; ~4096 workgroups in flight fill the 256 CUs
-        int bx = grid_for(n, kRqBlock * 16, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
-        const dim3 grid(bx, n_rows), block(kRqBlock);
-        // rows whose candidates overflowed (big ties, e.g. the all-equal t=0 row) re-stream alone: give each
-        // row a wide grid; workgroups of the other rows exit at once
-        const dim3 grid_slow(grid_for(n, kRqBlock * 16, 1024), n_rows);
+        const int gy = row_list ? n_list : n_rows;       // a call on a row list launches exactly those rows
+        int bx = grid_for(n, kRqBlock * 16, 4096 / gy > 0 ? 4096 / gy : 1);
+        const dim3 grid(bx, gy), block(kRqBlock);
+        // rows whose candidates overflowed (big ties) re-stream alone; the workgroups of all other rows exit at
+        // once, and since that is the common case the grid stays modest (idle workgroups cost ~10 ns each)
+        const dim3 grid_slow(grid_for(n, kRqBlock * 16, slow_cap), gy);
         const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);  // <= 2 targets per quantile
         const size_t lds_first = 256 * sizeof(unsigned int);
         if (pass == 0) {
-            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, track_minmax);
+            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, track_minmax, row_n, row_list);
         } else if (pass < 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0, row_n, row_list);
         } else if (pass == 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0);
+            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0, row_n, row_list);
         } else {
-            hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, n_rows), block, lds_groups, s, pass, L.st, L.hist, L.aux, L.cand, cap);
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1, 0);
+            hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, gy), block, lds_groups, s, pass, L.st, L.hist, L.aux, L.cand, cap, row_list);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1, 0, row_n, row_list);
         }
     }
     if (pass == 3) hipLaunchKernelGGL(rq_flag_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, L.st, L.aux, n_rows, cap);
@@ -549,8 +918,9 @@ static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, 
     return MCR_OK;
 }
 
-int mcr_row_quantiles_scan(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
-                           uint64_t* counts, void* scratch, int device, void* hip_stream) {
+static int rq_scan_step(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
+                        uint64_t* counts, void* scratch, int device, void* hip_stream, int mode,
+                        const unsigned int* row_list, int n_list) {
     int rc = use_device(device);
     if (rc != MCR_OK) return rc;
     rc = rq_check(scratch, n_rows, 0, n_q);
@@ -564,22 +934,111 @@ int mcr_row_quantiles_scan(int32_t n_rows, int64_t n_total, const double* q, int
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
     const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);
-    hipLaunchKernelGGL(rq_scan_kernel, dim3(n_rows), dim3(64), lds_groups, (hipStream_t)hip_stream, n_total, pass, L.st, L.hist, a, out,
-                       (unsigned long long*)counts, L.aux);
+    hipLaunchKernelGGL(rq_scan_kernel, dim3(row_list ? n_list : n_rows), dim3(64), lds_groups, (hipStream_t)hip_stream, n_total, pass,
+                       L.st, L.hist, a, out, (unsigned long long*)counts, L.aux, mode, row_list);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rq_scan_kernel");
     return MCR_OK;
 }
 
-int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q,
-                      int32_t n_q, double* out, uint64_t* counts, void* scratch, int device, void* hip_stream) {
-    if (!rows || n <= 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
-    int rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+int mcr_row_quantiles_scan(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
+                           uint64_t* counts, void* scratch, int device, void* hip_stream) {
+    return rq_scan_step(n_rows, n_total, q, n_q, pass, out, counts, scratch, device, hip_stream, kRqQuantiles, nullptr, 0);
+}
+
+// The full radix select (8 digit passes) over rows of length n: all rows, or the n_list rows listed in row_list.
+static int rq_radix_select(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q, int32_t n_q,
+                           double* out, uint64_t* counts, void* scratch, int device, void* hip_stream, int mode,
+                           const unsigned int* row_n, const unsigned int* row_list, int n_list) {
+    int rc = MCR_OK;
     for (int pass = 0; pass < 8 && rc == MCR_OK; ++pass) {
-        rc = rq_hist_step(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream, /*track_minmax=*/1);
-        if (rc == MCR_OK) rc = mcr_row_quantiles_scan(n_rows, n, q, n_q, pass, out, counts, scratch, device, hip_stream);
+        rc = rq_hist_step(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream,
+                          /*track_minmax=*/mode == kRqQuantiles ? 1 : 0, row_n, row_list, n_list,
+                          /*slow_cap=*/mode == kRqQuantiles ? 512 : 32);   // the sample / candidate selects are short rows
+        if (rc == MCR_OK) rc = rq_scan_step(n_rows, n, q, n_q, pass, out, counts, scratch, device, hip_stream, mode, row_list, n_list);
     }
     return rc;
+}
+
+// Rows at least this long take the bracketed single pass (below it the extra launches cost more than the
+// three streaming passes they save).  MCR_RQ_BRACKET_MIN_N overrides it (tests force either route).
+static int64_t rq_bracket_min_n() {
+    const char* e = std::getenv("MCR_RQ_BRACKET_MIN_N");
+    if (e && *e) return (int64_t)std::strtoll(e, nullptr, 10);
+    return (int64_t)1 << 21;
+}
+
+static thread_local int g_last_fallback_rows = -1;
+int mcr_row_quantiles_last_fallback_rows(void) { return g_last_fallback_rows; }
+
+int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q,
+                      int32_t n_q, double* out, uint64_t* counts, void* scratch, int device, void* hip_stream) {
+    g_last_fallback_rows = -1;
+    if (!rows || n <= 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
+    int rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+    if (rc != MCR_OK) return rc;
+    if (n < rq_bracket_min_n() || n < 4096 || 2 * n_q >= 32)
+        return rq_radix_select(rows, row_stride, n_rows, n, q, n_q, out, counts, scratch, device, hip_stream, kRqQuantiles, nullptr, nullptr, 0);
+
+    rc = rq_check(scratch, n_rows, n, n_q);
+    if (rc != MCR_OK) return rc;
+    if (!q || !out || row_stride < n) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
+    for (int j = 0; j < n_q; ++j)
+        if (!(q[j] >= 0.0 && q[j] <= 1.0)) { set_error("quantile %d out of [0,1]", j); return MCR_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    const RqLayout L = rq_layout(scratch, n_rows, n);
+    RqArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_q = n_q;
+    for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
+    // (1) brackets from a sample: the first n/32 entries of every row (paths are exchangeable; an unlucky or
+    //     adversarial prefix only costs the affected rows the fallback below)
+    int64_t m = n / 32;
+    if (m < 65536) m = 65536;
+    if (m > n) m = n;
+    m &= ~(int64_t)1;
+    rc = rq_radix_select(rows, row_stride, n_rows, m, q, n_q, out, nullptr, scratch, device, hip_stream, kRqSample, nullptr, nullptr, 0);
+    if (rc != MCR_OK) return rc;
+    hipLaunchKernelGGL(rq_bracket_prep_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, L.st, L.br, (int)n_q, (int)n_rows, L.fb_count);
+    // (2) the one pass over the slab
+    const unsigned int bcap = rq_bracket_cand_cap(n);
+    {
+        const int bx = grid_for(n, kRqBlock * 16, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
+        const dim3 grid(bx, n_rows), block(kRqBlock);
+#define MCR_BRACKET(P) hipLaunchKernelGGL((rq_bracket_kernel<P>), grid, block, 0, s, rows, row_stride, n, L.br, L.bcand, bcap)
+        if (2 * n_q < 16) MCR_BRACKET(16);        // bound table: the next power of two above 2 * (intervals <= quantiles)
+        else MCR_BRACKET(32);
+#undef MCR_BRACKET
+    }
+    // (3) ranks among the candidates, then the select on the candidate buffers (ragged rows)
+    rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+    if (rc != MCR_OK) return rc;
+    hipLaunchKernelGGL(rq_resolve_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, n, a, L.br, L.st, L.row_n, L.row_fallback,
+                       L.fb_list, L.fb_count, (unsigned long long*)counts, bcap, (int)n_rows);
+    rc = rq_radix_select(L.bcand, (int64_t)bcap, n_rows, (int64_t)bcap, q, n_q, out, nullptr, scratch, device, hip_stream,
+                         kRqExplicit, L.row_n, nullptr, 0);
+    if (rc != MCR_OK) return rc;
+    hipLaunchKernelGGL(rq_finalize_kernel, dim3((n_rows * n_q + 255) / 256), dim3(256), 0, s, L.st, L.br, L.row_fallback, (int)n_q,
+                       (int)n_rows, out);
+    // (4) rows the brackets could not decide (a target outside its bracket, candidates overflowing on a wide tie
+    //     that straddles a bracket end, an all-NaN sample) take the full passes.  How many is only known on the
+    //     device: this route reads one word back (ONE stream synchronisation per call) rather than launch eight
+    //     passes of idle workgroups.
+    unsigned int n_fb = 0;
+    hipError_t e = hipMemcpyAsync(&n_fb, L.fb_count, sizeof(n_fb), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "bracketed row quantiles");
+    g_last_fallback_rows = (int)n_fb;
+    if (n_fb > 0) {
+        rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+        if (rc != MCR_OK) return rc;
+        rc = rq_radix_select(rows, row_stride, n_rows, n, q, n_q, out, counts, scratch, device, hip_stream, kRqQuantiles, nullptr,
+                             L.fb_list, (int)n_fb);
+        if (rc != MCR_OK) return rc;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "bracketed row quantiles");
+    return MCR_OK;
 }
 
 int mcr_minmax_success(const double* values, const uint8_t* success, int64_t n, double* minmax, int device, void* hip_stream) {

@@ -336,3 +336,77 @@ def test_batched_search_equals_one_probe_at_a_time():
     assert ra == rb and ea == eb
     assert b._speculation_slots(20_000) == 1
     assert max(calls_a) > 1 and len(calls_a) < len(calls_b) <= len(rb[2])   # fewer, wider calls
+
+
+def _rows_for_bracket_test(rng, n, stride):
+    rows = np.full((14, stride), 123.0)
+    rows[0, :n] = rng.normal(1e6, 3e5, n)
+    rows[1, :n] = rng.integers(0, 5, n).astype(float)                      # 5 giant ties: candidates overflow -> fallback
+    rows[2, :n] = np.where(rng.random(n) < 0.3, np.nan, rng.lognormal(0, 2, n))
+    rows[3, :n] = np.nan                                                    # all NaN
+    rows[4, :n] = -rng.lognormal(3, 1, n)
+    rows[5, :n] = 0.0                                                       # constant
+    rows[6, :n] = rng.choice([-np.inf, np.inf, 0.0, -0.0, 1e-300, -1e-300, 5.0], n)
+    rows[7, :n] = np.arange(n, dtype=float)                                 # sorted: the prefix sample is useless -> fallback
+    rows[8, :n] = rng.normal(0, 1, n) * 10.0 ** rng.integers(-8, 9, n)
+    rows[9, :n] = np.where(np.arange(n) < n // 16, np.nan, rng.lognormal(12, 1, n))   # the sample is mostly NaN
+    rows[10, :n] = np.where(rng.random(n) < 0.65, 0.0, rng.lognormal(10, 2, n))       # 65 % zeros + a continuous tail
+    rows[11, :n] = np.sort(rng.normal(0, 1, n))[::-1]                       # descending
+    rows[12, :n] = rng.normal(5e5, 1.0, n).round(0)                         # few distinct values around the median
+    rows[13, :n] = np.where(np.arange(n) < 70_000, np.nan, rng.normal(0, 1, n))       # sample has NO valid entry
+    return rows
+
+
+@pytest.mark.parametrize("n,stride", [(4096, 4096), (65_536, 65_600), (300_001, 300_032), (300_000, 300_001)])
+def test_bracketed_row_quantiles_match_pandas_exactly(n, stride, monkeypatch):
+    """The sample-bracketed single pass (forced here for short rows through MCR_RQ_BRACKET_MIN_N) returns bit for
+    bit what the full radix passes and pandas return — on rows its brackets decide and on rows that must fall
+    back (giant ties, sorted input, NaN-only sample, constant rows) — for the trajectory and the WR quantile sets
+    and for the extreme quantiles 0 and 1."""
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    rng = np.random.default_rng(n)
+    rows = _rows_for_bracket_test(rng, n, stride)
+    dev_rows = torch.as_tensor(rows, device="cuda")
+    for qs in (A.TRAJECTORY_QUANTILES, A.WR_QUANTILES, (0.0, 1.0, 0.5, 0.999, 0.001), tuple(np.linspace(0.03, 0.97, 16))):
+        exp = pd.DataFrame(rows[:, :n].T).quantile(list(qs), axis=0).T.to_numpy()
+        monkeypatch.setenv("MCR_RQ_BRACKET_MIN_N", "1")
+        got, counts = A.row_quantiles(dev_rows, n, qs)
+        n_fb = A.last_fallback_rows()
+        # rows 3 and 13 have no valid entry in their sample; the sorted rows 7 and 11 defeat a prefix sample unless
+        # the sample is the whole row; a bracket that straddles two giant ties (rows 1, 6, 12) overflows the candidate
+        # buffer.  A bracket INSIDE one tie (rows 5, 10, most of 1) is a one-key interval, not a fallback; the
+        # continuous rows (0, 2, 4, 8, 9) never fall back.
+        if len(qs) < 16:
+            assert 2 <= n_fb <= 9, n_fb
+        else:
+            assert n_fb == -1            # 16 quantiles: 32 bounds do not fit the bound table, plain radix route
+        monkeypatch.setenv("MCR_RQ_BRACKET_MIN_N", str(2**40))
+        plain, counts_plain = A.row_quantiles(dev_rows, n, qs)
+        assert A.last_fallback_rows() == -1
+        assert np.array_equal(plain, exp, equal_nan=True)
+        bad = [(r, got[r], exp[r]) for r in range(rows.shape[0]) if not np.array_equal(got[r], exp[r], equal_nan=True)]
+        assert not bad, (n, qs, bad[:3])
+        assert counts.tolist() == counts_plain.tolist() == (~np.isnan(rows[:, :n])).sum(axis=1).tolist()
+
+
+def test_bracketed_row_quantiles_at_the_default_threshold():
+    """3 x 2^22 entries: above the default threshold, so the default route is the bracketed one; equals numpy."""
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    n = 1 << 22
+    rng = np.random.default_rng(3)
+    rows = np.empty((3, n))
+    rows[0] = rng.lognormal(14, 1.2, n)
+    rows[1] = np.where(rng.random(n) < 0.2, np.nan, rng.normal(4.0, 1.5, n))
+    rows[2] = 1.0e6
+    got, counts = A.row_quantiles(torch.as_tensor(rows, device="cuda"), n, A.TRAJECTORY_QUANTILES)
+    assert A.last_fallback_rows() == 0       # bracketed route, every row decided on its candidates
+    for r in range(3):
+        v = rows[r][~np.isnan(rows[r])]
+        assert np.array_equal(got[r], np.quantile(v, A.TRAJECTORY_QUANTILES)), r
+        assert counts[r] == v.size

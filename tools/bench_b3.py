@@ -65,8 +65,9 @@ def main():
         "K1_algorithmic_write_bytes": bytes_k1, "K1_write_GBps": bytes_k1 / ms_k1 / 1e6,
         "K3_traj_ms": ms_q, "K3_real_ms": ms_qr, "K3_wr_ms": ms_qw,
         "K3_rows": 2 * T + ry, "K3_total_ms": ms_q + ms_qr + ms_qw,
-        "K3_algorithmic_read_bytes_8pass": 8 * bytes_q_pass * (2 * T + ry),
-        "K3_read_GBps_8pass": 8 * bytes_q_pass * (2 * T + ry) / (ms_q + ms_qr + ms_qw) / 1e6,
+        "K3_slab_bytes": bytes_q_pass * (2 * T + ry),
+        "K3_slab_reads_per_second_GBps": bytes_q_pass * (2 * T + ry) / (ms_q + ms_qr + ms_qw) / 1e6,
+        "K3_fallback_rows": A.last_fallback_rows(),
         "K2_hist100_ms": ms_h, "K2_hist60_ms": ms_h60, "K2_algorithmic_bytes": 2 * 9 * n,
         "K2_GBps": 2 * 9 * n / ms_h / 1e6,
         "success_probability": float(b.counters[0].item()) / n,

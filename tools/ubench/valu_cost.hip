@@ -49,6 +49,12 @@ KERNEL(mad_u64_u32, uint64_t, seed + threadIdx.x + c, asm volatile("v_mad_u64_u3
 KERNEL(cvt_f64_u32, double, seed + threadIdx.x + c, asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(x) : "v"((uint32_t)threadIdx.x)))
 KERNEL(cmp_f64, double, seed + threadIdx.x + c, asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(x), "v"(seed) : "vcc"))
 KERNEL(mov_b32, uint32_t, seed + threadIdx.x + c, asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(seed)))
+KERNEL(cmp_lt_u64, uint64_t, seed + threadIdx.x + c, asm volatile("v_cmp_lt_u64_e64 s[20:21], %0, %1" : : "v"(x), "v"(seed) : "s20", "s21"))
+KERNEL(cmp_lt_u32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1" : : "v"(x), "v"(seed) : "s20", "s21"))
+KERNEL(cmp_eq_u64, uint64_t, seed + threadIdx.x + c, asm volatile("v_cmp_eq_u64_e64 s[20:21], %0, %1" : : "v"(x), "v"(seed) : "s20", "s21"))
+KERNEL(cmp_addc_u64, uint64_t, seed + threadIdx.x + c, { uint32_t lo32 = (uint32_t)x; asm volatile("v_cmp_lt_u64_e64 s[20:21], %1, %2\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(lo32) : "v"(x), "v"(seed) : "s20", "s21", "vcc"); x = (x & 0xFFFFFFFF00000000ull) | lo32; })
+KERNEL(cmp_addc_u32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(x) : "v"(seed) : "s20", "s21", "vcc"))
+KERNEL(addc_only, uint32_t, seed + threadIdx.x + c, asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(x) : : "vcc"))
 
 template <typename T>
 static void run(const char* name, void (*k)(T*, T), T seed) {
@@ -84,5 +90,7 @@ int main() {
     RUN(fma_f32, float, 1.0000001f); RUN(add_u32, uint32_t, 3); RUN(xor_b32, uint32_t, 3); RUN(mul_lo_u32, uint32_t, 3);
     RUN(mul_hi_u32, uint32_t, 3); RUN(cndmask_b32, uint32_t, 3); RUN(mad_u64_u32, uint64_t, 3); RUN(cvt_f64_u32, double, 1.0);
     RUN(cmp_f64, double, 1.0); RUN(mov_b32, uint32_t, 3);
+    RUN(cmp_lt_u64, uint64_t, 3); RUN(cmp_lt_u32, uint32_t, 3); RUN(cmp_eq_u64, uint64_t, 3);
+    RUN(cmp_addc_u64, uint64_t, 3); RUN(cmp_addc_u32, uint32_t, 3); RUN(addc_only, uint32_t, 3);
     return 0;
 }
