@@ -24,7 +24,8 @@ def label(kernel_name: str):
         return "K1 path_kernel<0,...> (count-only, 1e6 paths x 833 months)"
     if "path_kernel<2" in k:
         return "K1 path_kernel<2,...> (full output, 4e6 paths x 555 months)"
-    for tag, name in (("rq_hist", "K3 rq_hist_kernel"), ("rq_cand", "K3 rq_cand_hist_kernel"), ("rq_scan", "K3 rq_scan_kernel")):
+    for tag, name in (("rq_bracket_kernel", "K3 rq_bracket_kernel (the one pass over the slab)"), ("rq_hist", "K3 rq_hist_kernel"),
+                      ("rq_cand", "K3 rq_cand_hist_kernel"), ("rq_scan", "K3 rq_scan_kernel")):
         if tag in k:
             return name
     if "hist_kernel" in k or "minmax" in k:
@@ -49,6 +50,7 @@ def main(src: str, dst: str) -> None:
     k0 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<0"))
     k2 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<2"))
     k3 = summ["K3 rq_hist_kernel"]
+    kb = summ["K3 rq_bracket_kernel (the one pass over the slab)"]
     m = lambda k, c: k[c]["mean_per_launch"]
     wave_months = (PATHS_COUNT / 64) * MONTHS_COUNT
     stat_rows = list(csv.DictReader(open(stats)))
@@ -68,7 +70,15 @@ def main(src: str, dst: str) -> None:
         "K1_full_algorithmic_write_bytes": alg_full,
         "K1_full_write_efficiency_algorithmic_over_measured": alg_full / (m(k2, "WRITE_SIZE") * 1024),
         "K3_hist_FETCH_SIZE_x2_bytes_per_launch_mean": 2 * m(k3, "FETCH_SIZE") * 1024,
+        "K3_bracket_slab_bytes_algorithmic": 8 * PATHS_FULL * (2 * T_FULL + RY_FULL),
+        "K3_bracket_FETCH_SIZE_x2_bytes_per_launch": 2 * m(kb, "FETCH_SIZE") * 1024,
+        "K3_bracket_WRITE_SIZE_bytes_per_launch": m(kb, "WRITE_SIZE") * 1024,
     }
+    kb_ms = next(float(r["AverageNs"]) for r in stat_rows if "rq_bracket_kernel" in r["Name"]) / 1e6
+    derived["K3_bracket_avg_ms_from_kernel_stats"] = kb_ms
+    derived["K3_bracket_achieved_TBps"] = derived["K3_bracket_slab_bytes_algorithmic"] / (kb_ms * 1e-3) / 1e12
+    derived["K3_bracket_traffic_over_algorithmic"] = (derived["K3_bracket_FETCH_SIZE_x2_bytes_per_launch"] +
+                                                        derived["K3_bracket_WRITE_SIZE_bytes_per_launch"]) / derived["K3_bracket_slab_bytes_algorithmic"]
     json.dump({
         "command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "
                    "(separate passes: SQ, SQ instruction mix, FETCH_SIZE, WRITE_SIZE; tools/collect_profiles.sh)",
