@@ -190,3 +190,34 @@ def run_sharded_bands(params, rng_or_seed, stream_id: int, n_total: int, working
         reduce_bins=all_reduce_sum_ if world > 1 else None,
     )
     return out
+
+
+def run_sharded_histogram(params, rng_or_seed, stream_id: int, n_total: int, working_months: int, n_bins: int = 100,
+                          value_range: Optional[Tuple[float, float]] = None):
+    """BASELINE configs[3] on N GPUs (success counts + histogram of successful final balances, no trajectories):
+    every rank simulates its shard of the global path range with the summary-output kernel (49 B/path, kept in its
+    own HBM), then the counter block and the histogram bins are summed across ranks.  With ``value_range`` the bin
+    edges are fixed and the exchange is the two sum all-reduces only; without it the cohort's min/max are reduced
+    first (``np.histogram`` semantics on the union of the shards).  Returns the same dict on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    from . import aggregation as A
+    from . import engine as E
+
+    rank, world = (dist.get_rank(), dist.get_world_size()) if is_active() else (0, 1)
+    begin, count = shard_range(int(n_total), rank, world)
+    dev = torch.cuda.current_device()
+    batch = E.DeviceBatch(params, working_months, max(count, 1), want="summary", device=dev)
+    if count > 0:
+        batch.launch(rng_or_seed, stream_id, begin, count)
+    vec = batch.reduce_vec
+    if world > 1:
+        all_reduce_sum_(vec)
+    red = unpack_counts(vec.cpu().numpy(), batch.sizes.retirement_years)
+    bins, edges = A.success_histogram(
+        batch.summary["final_balance"][:count], batch.success[:count], n_bins, value_range=value_range,
+        reduce_range=all_reduce_minmax_ if (world > 1 and value_range is None) else None,
+        reduce_bins=all_reduce_sum_ if world > 1 else None,
+    )
+    return {"counts": red, "shard": (begin, count), "hist_bins": bins, "hist_edges": edges}

@@ -66,6 +66,14 @@ def main():
     res["counts_ok"] = bool(sh["counts"].success == int(whole.counters[0].item()) and sh["counts"].paths == n_paths
                             and sh["counts"].ruin_year_bins.tolist() == whole.ruin_year_bins.cpu().tolist())
     res["success"] = sh["counts"].success
+    # ---- (2b) counts + histogram only (no trajectories): data-ranged and fixed-range bins
+    hh = D.run_sharded_histogram(p, 2024, 1, n_paths, wm, n_bins=60)
+    res["hist_only_equal"] = bool(hh["hist_bins"].tolist() == hb.tolist() and np.array_equal(hh["hist_edges"], he)
+                                  and hh["counts"].success == sh["counts"].success and hh["counts"].paths == n_paths)
+    fixed = (0.0, float(he[-1]) * 1.5)
+    hf = D.run_sharded_histogram(p, 2024, 1, n_paths, wm, n_bins=60, value_range=fixed)
+    hb_f, he_f = A.success_histogram(whole.summary["final_balance"], whole.success, 60, value_range=fixed)
+    res["hist_fixed_equal"] = bool(hf["hist_bins"].tolist() == hb_f.tolist() and np.array_equal(hf["hist_edges"], he_f))
     # ---- (3) the drop-in class, transparently sharded: search probe + final run
     from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
 

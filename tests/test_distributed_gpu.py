@@ -41,6 +41,7 @@ def test_sharded_quantiles_and_bands_equal_unsharded(tmp_path, world):
         assert r["quantiles_equal"] and r["counts_equal"], r
         assert r["bands_equal"] and r["hist_equal"] and r["counts_ok"], r
         assert r["success"] == res[0]["success"]
+        assert r["hist_only_equal"] and r["hist_fixed_equal"], r
         assert r["class_summary_equal"] and r["class_bands_equal"] and r["class_samples_equal"] and r["class_probe_equal"], r
         assert r["class_probe_many_by_candidate"] and r["class_probe_many_by_range"] and r["class_speculation_slots"], r
         assert r["class_search_replays_reference"] and r["class_search_batched"], r
