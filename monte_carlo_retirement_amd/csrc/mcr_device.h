@@ -70,6 +70,10 @@ __device__ __forceinline__ LaneParams lane_params(const DevParams& P) {
 // month, stream_id), key = (seed_lo, seed_hi).  The key schedule is wave-uniform (scalar ALU).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    // The key is wave-uniform.  Left alone, the compiler hoists all ten round keys out of the month loop and then
+    // spills them (18 SGPRs -> v_readlane + s_nop per use); behind this barrier it bumps the key with two scalar adds
+    // per round instead, which are free next to the VALU work.
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
