@@ -32,6 +32,7 @@ namespace mcr {
 constexpr int kRqMaxQ = 16;            // quantiles per call
 constexpr int kRqMaxT = 2 * kRqMaxQ;   // order statistics per row (lower/upper neighbour of each)
 constexpr int kRqBlock = 256;
+constexpr int kRqScanBlock = 256;    // rq_scan_kernel: one workgroup per row (targets use the first <= 32 threads)
 
 struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
     unsigned long long n_valid;          // non-NaN entries (= wr_df.count(axis=1) for WR rows)
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow*
 
 // Per row: advance every target by one digit, regroup, clear the histograms; after the last pass
 // interpolate (NumPy `linear`) and write the quantiles.
-__global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow* st, unsigned int* hist,
+__global__ __launch_bounds__(kRqScanBlock) void rq_scan_kernel(int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                     const RqArgs args, double* out, unsigned long long* counts,
                                                     unsigned int* aux, int mode,
                                                     const unsigned int* __restrict__ row_list) {
@@ -286,16 +287,18 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
     unsigned int* l_state = reinterpret_cast<unsigned int*>(&S);
     unsigned int* gh = hist + (size_t)row * kRqMaxT * 256;
     const int t = threadIdx.x;
-    for (int k = t; k < kRowWords; k += 64) l_state[k] = g_state[k];
+    for (int k = t; k < kRowWords; k += kRqScanBlock) l_state[k] = g_state[k];
     {
         // (groups beyond the row's current count hold zeros: reading up to the call's maximum needs no dependent load)
         const int ng = pass == 0 ? 1 : 2 * args.n_q;
-        for (int k = t; k < ng * 256; k += 64) sh[k] = gh[k];
+        const uint4* gh4 = reinterpret_cast<const uint4*>(gh);   // 16-byte loads: the block is 32 KB-aligned per row
+        uint4* sh4 = reinterpret_cast<uint4*>(sh);
+        for (int k = t; k < ng * 64; k += kRqScanBlock) sh4[k] = gh4[k];
     }
     __syncthreads();
     auto store_state = [&]() {
         __syncthreads();
-        for (int k = t; k < kRowWords; k += 64) g_state[k] = l_state[k];
+        for (int k = t; k < kRowWords; k += kRqScanBlock) g_state[k] = l_state[k];
     };
     if (pass == 0 && t == 0 && mode != kRqExplicit) {
         const unsigned long long m = (unsigned long long)n - (unsigned long long)aux[2 * row];
@@ -339,25 +342,48 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
     __syncthreads();
     if (S.const_row) {
         if (pass == 0) {
-            for (int k = t; k < 256; k += 64) gh[k] = 0u;
+            for (int k = t; k < 256; k += kRqScanBlock) gh[k] = 0u;
             if (t < args.n_q) out[(size_t)row * args.n_q + t] = value_of(S.kmin);  // lerp(a, a, g) = a
             store_state();
         }
         return;
     }
     const int nt = S.n_targets;
-    if (t < nt) {
-        const int g = S.group_of[t];
-        const unsigned int* h = sh + g * 256;
-        unsigned long long rank = S.rank[t], cum = 0;
-        int d = 0;
-        for (; d < 255; ++d) {
-            const unsigned long long c = h[d];
-            if (rank < cum + c) break;
-            cum += c;
+    // each target: the digit d whose bin holds its rank, i.e. the first d with rank < h[0] + ... + h[d] (255 if none).
+    // One wave per target at a time: a lane sums 4 bins, a wave scan finds the lane, that lane walks its 4 bins.
+    for (int tg = t >> 6; tg < nt; tg += kRqScanBlock / 64) {
+        const int lane = t & 63;
+        const int g = S.group_of[tg];
+        const unsigned int* h = sh + g * 256 + 4 * lane;
+        const unsigned long long c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
+        const unsigned long long rank = S.rank[tg];
+        unsigned long long incl = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
+            incl += lane >= off ? up : 0ull;
         }
-        S.rank[t] = rank - cum;
-        new_prefix[t] = (S.prefix[g] << 8) | (unsigned long long)d;
+        const unsigned long long excl = incl - (c0 + c1 + c2 + c3);
+        const unsigned long long hit = __ballot(rank >= excl && rank < incl);   // at most one lane
+        int d = 255;
+        unsigned long long cum = 0ull;
+        if (hit) {
+            const int L = __ffsll((long long)hit) - 1;
+            if (lane == L) {
+                cum = excl;
+                d = 4 * lane;
+                if (rank >= cum + c0) { cum += c0; ++d; if (rank >= cum + c1) { cum += c1; ++d; if (rank >= cum + c2) { cum += c2; ++d; } } }
+            }
+            d = __shfl(d, L, 64);
+            cum = (unsigned long long)__shfl((long long)cum, L, 64);
+        } else {   // rank beyond the histogram's total: the scan ends in the last bin, below which lie all the others
+            const unsigned long long total = (unsigned long long)__shfl((long long)incl, 63, 64);
+            cum = total - (unsigned long long)sh[g * 256 + 255];
+        }
+        if (lane == 0) {
+            S.rank[tg] = rank - cum;
+            new_prefix[tg] = (S.prefix[g] << 8) | (unsigned long long)d;
+        }
     }
     __syncthreads();
     const int old_groups = S.n_groups;
@@ -377,7 +403,10 @@ __global__ __launch_bounds__(64) void rq_scan_kernel(int64_t n, int pass, RqRow*
     if (t < nt) S.group_of[t] = grp_of[t];
     if (t < n_grp && nt > 0) S.prefix[t] = grp_prefix[t];
     if (t == 0) S.n_groups = n_grp;
-    for (int k = t; k < old_groups * 256; k += 64) gh[k] = 0u;  // ready for the next pass / call
+    {   // ready for the next pass / call
+        uint4* gz = reinterpret_cast<uint4*>(gh);
+        for (int k = t; k < old_groups * 64; k += kRqScanBlock) gz[k] = uint4{0u, 0u, 0u, 0u};
+    }
     __syncthreads();
     if (pass == 7) {
         if (t < nt) S.value[t] = value_of(new_prefix[t]);
@@ -934,7 +963,7 @@ static int rq_scan_step(int32_t n_rows, int64_t n_total, const double* q, int32_
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
     const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);
-    hipLaunchKernelGGL(rq_scan_kernel, dim3(row_list ? n_list : n_rows), dim3(64), lds_groups, (hipStream_t)hip_stream, n_total, pass,
+    hipLaunchKernelGGL(rq_scan_kernel, dim3(row_list ? n_list : n_rows), dim3(kRqScanBlock), lds_groups, (hipStream_t)hip_stream, n_total, pass,
                        L.st, L.hist, a, out, (unsigned long long*)counts, L.aux, mode, row_list);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rq_scan_kernel");
