@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCR_ABI_VERSION 2
+#define MCR_ABI_VERSION 3
 #define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
 #define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */

@@ -12,7 +12,7 @@ import os
 import threading
 from typing import Optional
 
-MCR_ABI_VERSION = 2
+MCR_ABI_VERSION = 3
 MCR_MAX_STREAMS = 16
 MCR_N_COUNTERS = 2
 MCR_N_STAT_ROWS = 4
