@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     }
     const int G = FIRST ? 1 : st[row].n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
-    if (threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
+    if ((int)threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
     if (threadIdx.x == 0) { lnan = 0u; stage_n = 0u; }
     __syncthreads();
     const double* r = rows + (int64_t)row * row_stride;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow*
     if (aux[2 * row + 1] || S.const_row || S.n_targets == 0) return;
     const int G = S.n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
-    if (threadIdx.x < G) lpref[threadIdx.x] = S.prefix[threadIdx.x];
+    if ((int)threadIdx.x < G) lpref[threadIdx.x] = S.prefix[threadIdx.x];
     __syncthreads();
     const unsigned int cnt = S.cand_count;
     const unsigned long long* crow = cand + (size_t)row * cand_cap;
