@@ -231,6 +231,7 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
 #define MCR_HELPER_MATH_SQRT 7     /* in[1]=(w)            out[1]=sqrt(w)                             */
 #define MCR_HELPER_MATH_NEG2LOG 8  /* in[1]=(x as uint32)  out[1]=-2 ln((x+0.5) 2^-32)                */
 #define MCR_HELPER_MATH_SINCOS 9   /* in[1]=(x as uint32)  out[2]=(sin, cos)(2 pi (x+0.5) 2^-32)      */
+#define MCR_HELPER_MATH_DIV_PATH 10 /* in[2]=(a,b)         out[1]=a/b as the path kernel divides (1 Newton step) */
 /* Evaluates helper `which` ON THE DEVICE for n rows (host buffers, row-major). */
 int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out,
                          int64_t n, int device);

@@ -34,6 +34,7 @@ MCR_HELPER_MATH_DIV = 6
 MCR_HELPER_MATH_SQRT = 7
 MCR_HELPER_MATH_NEG2LOG = 8
 MCR_HELPER_MATH_SINCOS = 9
+MCR_HELPER_MATH_DIV_PATH = 10
 _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_WITHDRAW: (5, 4),
     MCR_HELPER_NLV: (4, 1),
@@ -45,6 +46,7 @@ _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_MATH_SQRT: (1, 1),
     MCR_HELPER_MATH_NEG2LOG: (1, 1),
     MCR_HELPER_MATH_SINCOS: (1, 2),
+    MCR_HELPER_MATH_DIV_PATH: (2, 1),
 }
 
 

@@ -172,12 +172,12 @@ template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
                                          double& gross_out, double& net_out) {
     const bool skip = (bal <= kEps) || (net_target <= 0.0);              // :218
-    const double inv_bal = recip_nr(bal);                                // shared by the two divisions by bal
+    const double inv_bal = recip_nr<STRICT>(bal);                        // shared by the two divisions by bal
     double gross;
     if (TAXED) {
         const double gain_fraction = div_by(fmax(0.0, bal - cb), bal, inv_bal);  // :221
         const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
-        gross = fmin(fdiv(net_target, net_fraction), bal);               // :228-231
+        gross = fmin(fdiv<STRICT>(net_target, net_fraction), bal);       // :228-231
     } else {
         gross = fmin(net_target, bal);                                   // net_fraction = max(eps, 1 - g*0) = 1; t / 1 = t
     }
@@ -219,13 +219,13 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     const double drift = sell1 ? drift1 : drift2;
     const double alloc_s = sell1 ? P.alloc1 : P.alloc2;            // the SOLD asset's own weight (:309,:337)
     const double rate_s = sell1 ? P.real_rate1 : P.real_rate2;
-    const double inv_bs = recip_nr(bs);                            // shared by the two divisions by bs
+    const double inv_bs = recip_nr<STRICT>(bs);                    // shared by the two divisions by bs
     double gross_sale;
     if (TAXED) {
         const double gain_fraction = div_by(fmax(0.0, bs - cs), bs, inv_bs);  // :301 / :329
         const double tax_per_dollar = gain_fraction * rate_s;      // :302-306
         const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
-        gross_sale = fmin(bs, fdiv(drift, denom));                 // :311
+        gross_sale = fmin(bs, fdiv<STRICT>(drift, denom));         // :311
     } else {
         gross_sale = fmin(bs, drift);                              // tax_per_dollar = 0, denom = 1, drift / 1 = drift
     }
@@ -272,7 +272,7 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
         if (cap > kEps && pay > 0.0) {                                // :408
-            const double share1 = fdiv(cap1, cap);                    // :409
+            const double share1 = fdiv<STRICT>(cap1, cap);            // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
             withdraw<STRICT, TAXED>(b1, c1, pay * share1, L.real_rate1, g, net1);  // :411-419

@@ -200,14 +200,14 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmax(0.0, fmin(need, cap));                 // :739-742
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
-                    const double prop1 = cap > kEps ? fdiv(cap1, cap) : P.alloc1;     // :750-754
+                    const double prop1 = cap > kEps ? fdiv<false>(cap1, cap) : P.alloc1;  // :750-754
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
                     withdraw<false, TAXED>(b1, c1, target * prop1, L.real_rate1, gw1, nw1);  // :757-765
                     tg1 += gw1;                                                       // :766
                     withdraw<false, TAXED>(b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg2 += gw2;                                                       // :777
-                    if (kSummary) treal += fdiv((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
+                    if (kSummary) treal += fdiv<false>((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
                     rebalance<false, TAXED>(L, b1, c1, b2, c2);                       // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
@@ -344,6 +344,7 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
         }
         case MCR_HELPER_MATH_EXP: out[i] = fexp(in[i], tab); break;
         case MCR_HELPER_MATH_DIV: out[i] = fdiv(in[2 * i], in[2 * i + 1]); break;
+        case MCR_HELPER_MATH_DIV_PATH: out[i] = fdiv<false>(in[2 * i], in[2 * i + 1]); break;
         case MCR_HELPER_MATH_SQRT: out[i] = fsqrt(in[i]); break;
         case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab); break;
         case MCR_HELPER_MATH_SINCOS: {
@@ -849,6 +850,7 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
         case MCR_HELPER_MONTHLY_GROSS: n_in = 3; n_out = 1; break;
         case MCR_HELPER_MATH_EXP: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_DIV: n_in = 2; n_out = 1; break;
+        case MCR_HELPER_MATH_DIV_PATH: n_in = 2; n_out = 1; break;
         case MCR_HELPER_MATH_SQRT: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_NEG2LOG: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_SINCOS: n_in = 1; n_out = 2; break;

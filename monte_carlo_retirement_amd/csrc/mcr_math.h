@@ -11,7 +11,7 @@
 //   fexp              exp(x), |x| < 700: 2^(k/64) table (LDS) + degree-6 polynomial, <= ~1.5 ulp.
 //   neg2_log_u32      -2 ln((x+0.5) 2^-32) straight from the Philox integer: 128-entry table of
 //                     (1/c, -2 ln c) + degree-6 series, <= 1.5 ulp of the result (Box-Muller radius^2).
-//   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 2 corrections, <= 1 ulp.
+//   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 1 correction, <= 1 ulp.
 //   sincos_u32        sin/cos(2 pi (x+0.5) 2^-32): top 8 bits index a 256-entry (sin,cos) table of
 //                     bin centres, the low 24 bits give |delta| <= pi/256, rotated with short series;
 //                     absolute error < 3e-16.  (All bounds measured on the device: tests/test_gpu_math.py.)
@@ -32,13 +32,19 @@ __device__ __forceinline__ void load_math_tables(double* lds_tab, int tid, int n
     for (int i = tid; i < kTabDoubles; i += nthreads) lds_tab[i] = kMathTab[i];
 }
 
-// 1/b to full precision: v_rcp_f64 seed + two Newton steps (the core of LLVM's IEEE fdiv lowering)
+// 1/b: v_rcp_f64 seed + Newton steps.  FULL = two steps (the core of LLVM's IEEE fdiv lowering; with div_by below the
+// quotient is bit-identical to `a / b`).  FULL = false = ONE step, used inside the path: y is then good to ~2^-50 and
+// the residual correction of div_by squares that, so the quotient is still the correctly rounded one except when
+// a / b lies within ~2^-100 (relative) of a rounding boundary — never observed (tests/test_gpu_math.py).
+template <bool FULL = true>
 __device__ __forceinline__ double recip_nr(double b) {
     double y = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, y, 1.0);
     y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
+    if (FULL) {
+        e = __builtin_fma(-b, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
     return y;
 }
 // a / b given y = recip_nr(b): quotient estimate + one residual correction (== v_div_fmas unscaled)
@@ -47,7 +53,8 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
     const double r = __builtin_fma(-b, q, a);
     return __builtin_fma(r, y, q);
 }
-__device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr(b)); }
+template <bool FULL = true>
+__device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr<FULL>(b)); }
 
 __device__ __forceinline__ double fexp(double x, const double* tab) {
     const double kf = __builtin_rint(x * k64OverLn2);
@@ -89,9 +96,7 @@ __device__ __forceinline__ double fsqrt(double w) {  // w normal, > 0
     const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, w);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, w);
+    const double d = __builtin_fma(-g, g, w);   // the Goldschmidt step leaves g good to ~2^-50; this correction squares that
     return __builtin_fma(d, h, g);
 }
 

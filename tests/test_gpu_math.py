@@ -28,6 +28,21 @@ def test_division_is_correctly_rounded_in_the_balance_range():
     assert np.array_equal(got, a / b)
 
 
+def test_path_division_one_newton_step_is_still_correctly_rounded():
+    """Inside the path the reciprocal takes ONE Newton step (fdiv<false>): the residual correction squares its error, so
+    the quotient equals IEEE a/b except within ~2^-100 of a rounding boundary.  4 million random operand pairs over the
+    path's dynamic range, plus the near-1 and power-of-two neighbourhoods where reciprocal seeds are worst: no mismatch."""
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    a = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-8, 16, n)
+    b = rng.uniform(0.1, 1, n) * 10.0 ** rng.uniform(-7, 16, n) * rng.choice([-1.0, 1.0], n)
+    a[:200_000] = 1.0 + rng.uniform(-1e-9, 1e-9, 200_000)
+    b[:200_000] = 1.0 + rng.uniform(-1e-9, 1e-9, 200_000)
+    b[200_000:400_000] = 2.0 ** rng.integers(-20, 40, 200_000) * (1.0 + rng.choice([0.0, 2.0 ** -52, -2.0 ** -53], 200_000))
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_DIV_PATH, None, np.column_stack((a, b)))[:, 0]
+    assert np.array_equal(got, a / b), int((got != a / b).sum())
+
+
 def test_exp_within_1_5_ulp():
     x = np.concatenate([np.random.default_rng(2).uniform(-3, 3, 300_000), np.linspace(-20, 20, 50_001), [0.0, -0.0, 1e-300]])
     got = E.eval_helper_host(N.MCR_HELPER_MATH_EXP, None, x.reshape(-1, 1))[:, 0]
