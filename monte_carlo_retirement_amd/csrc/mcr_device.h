@@ -196,8 +196,8 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
     const bool dust = nb <= kEps;                                        // :245-247
     nb = dust ? 0.0 : nb;
     ncb = dust ? 0.0 : ncb;
-    bal = skip ? fmax(0.0, bal) : nb;                                    // :219
-    cb = skip ? fmax(0.0, cb) : ncb;
+    bal = skip ? (STRICT ? fmax(0.0, bal) : bal) : nb;                   // :219  (in the path bal, cb >= 0 already)
+    cb = skip ? (STRICT ? fmax(0.0, cb) : cb) : ncb;
     gross_out = skip ? 0.0 : gross;
     net_out = skip ? 0.0 : net_cash;
 }

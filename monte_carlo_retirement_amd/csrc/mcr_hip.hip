@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     const double cap1 = net_liquidation_value<false, TAXED>(b1, c1, L.real_rate1);  // :726-731
                     const double cap2 = net_liquidation_value<false, TAXED>(b2, c2, L.real_rate2);  // :732-737
                     const double cap = cap1 + cap2;                                   // :738
-                    const double target = fmax(0.0, fmin(need, cap));                 // :739-742
+                    const double target = fmin(need, cap);                            // :739-742 (need, cap >= 0: the max(0, .) is a no-op)
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
                     const double prop1 = cap > kEps ? fdiv<false>(cap1, cap) : P.alloc1;  // :750-754
                     const double prop2 = 1.0 - prop1;                                 // :755
