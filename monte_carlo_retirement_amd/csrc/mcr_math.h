@@ -8,7 +8,7 @@
 //   fdiv / recip_nr   the IEEE division sequence without v_div_scale/v_div_fixup: bit-identical to
 //                     `a / b` whenever no exponent scaling is needed (balances live in 1e-6..1e15);
 //                     the Newton reciprocal is shared by quotients with the same divisor.
-//   fexp              exp(x), |x| < 700: 2^(k/64) table (LDS) + degree-6 polynomial, <= ~1.5 ulp.
+//   fexp              exp(x), |x| < 700: 2^(k/512) table (LDS, 4 KB) + degree-4 polynomial, <= ~1.5 ulp.
 //   neg2_log_u32      -2 ln((x+0.5) 2^-32) straight from the Philox integer: 128-entry table of
 //                     (1/c, -2 ln c) + degree-6 series, <= 1.5 ulp of the result (Box-Muller radius^2).
 //   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 1 correction, <= 1 ulp.
@@ -25,7 +25,7 @@
 
 namespace mcr {
 
-constexpr int kMathTabBytes = kTabDoubles * (int)sizeof(double);  // 6656 B of LDS
+constexpr int kMathTabBytes = kTabDoubles * (int)sizeof(double);  // 10 240 B of LDS
 
 // every thread of a kBlockThreads-wide workgroup calls this once; caller syncs afterwards
 __device__ __forceinline__ void load_math_tables(double* lds_tab, int tid, int nthreads) {
@@ -57,18 +57,16 @@ template <bool FULL = true>
 __device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr<FULL>(b)); }
 
 __device__ __forceinline__ double fexp(double x, const double* tab) {
-    const double kf = __builtin_rint(x * k64OverLn2);
-    double r = __builtin_fma(-kf, kLn2Over64Hi, x);
-    r = __builtin_fma(-kf, kLn2Over64Lo, r);
+    const double kf = __builtin_rint(x * kExpScale);
+    double r = __builtin_fma(-kf, kExpStepHi, x);      // exact: kf < 2^20 and the step's low 21 bits are zero
+    r = __builtin_fma(-kf, kExpStepLo, r);
     const int k = (int)kf;
-    const double t = tab[kTabExp2 + (k & 63)];
-    // e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24 + r^3/120 + r^4/720), |r| <= ln2/128
-    double p = __builtin_fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    p = __builtin_fma(r, p, 1.0 / 24.0);
-    p = __builtin_fma(r, p, 1.0 / 6.0);
+    const double t = tab[kTabExp2 + (k & ((1 << kExp2Bits) - 1))];
+    // e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24), |r| <= ln2/1024: the next term r^5/120 < 1.2e-18
+    double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
     p = __builtin_fma(r, p, 0.5);
     p = __builtin_fma(r * r, p, r);
-    return __builtin_ldexp(__builtin_fma(t, p, t), k >> 6);
+    return __builtin_ldexp(__builtin_fma(t, p, t), k >> kExp2Bits);
 }
 
 __device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab) {
