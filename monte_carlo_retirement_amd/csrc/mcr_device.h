@@ -164,7 +164,9 @@ __device__ __forceinline__ double net_liquidation_value(double bal, double cb, d
         const double tax = fmax(0.0, bal - cb) * rate;
         v = STRICT ? fmax(0.0, bal - tax) : bal - tax;  // tax <= bal when cb >= 0, rate <= 1
     }
-    return bal <= kEps ? 0.0 : v;
+    if (STRICT) return bal <= kEps ? 0.0 : v;
+    if (bal <= kEps) { asm volatile(""); v = 0.0; }   // path form: exec-masked move instead of a select (see withdraw)
+    return v;
 }
 
 // _calculate_withdrawal_and_update (:201-254), branch-free.
@@ -194,12 +196,22 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
     double nb = STRICT ? fmax(0.0, bal - gross) : bal - gross;           // :243
     double ncb = STRICT ? fmax(0.0, cb - basis_removed) : cb - basis_removed;  // :244
     const bool dust = nb <= kEps;                                        // :245-247
-    nb = dust ? 0.0 : nb;
-    ncb = dust ? 0.0 : ncb;
-    bal = skip ? (STRICT ? fmax(0.0, bal) : bal) : nb;                   // :219  (in the path bal, cb >= 0 already)
-    cb = skip ? (STRICT ? fmax(0.0, cb) : cb) : ncb;
-    gross_out = skip ? 0.0 : gross;
-    net_out = skip ? 0.0 : net_cash;
+    if (STRICT) {
+        nb = dust ? 0.0 : nb;
+        ncb = dust ? 0.0 : ncb;
+        bal = skip ? fmax(0.0, bal) : nb;                                // :219
+        cb = skip ? fmax(0.0, cb) : ncb;
+        gross_out = skip ? 0.0 : gross;
+        net_out = skip ? 0.0 : net_cash;
+    } else {
+        // Path form: the same selections as exec-masked moves.  A 64-bit select is two v_cndmask at a full issue slot
+        // each; a move under an exec mask costs about half of that, and the scalar mask bookkeeping is free next to
+        // the VALU work.  (The empty asm keeps the compiler from converting the branches back into selects.)
+        double rb = nb, rc = ncb, rg = gross, rn = net_cash;
+        if (dust) { asm volatile(""); rb = 0.0; rc = 0.0; }
+        if (skip) { asm volatile(""); rb = bal; rc = cb; rg = 0.0; rn = 0.0; }   // bal, cb >= 0 already
+        bal = rb; cb = rc; gross_out = rg; net_out = rn;
+    }
 }
 
 // _rebalance_portfolio (:274-359), branch-free: the over-weight asset is the seller.
@@ -243,16 +255,26 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     double nbb = bb + net_purchase;                                // :324
     double ncb = cbuy + net_purchase;                              // :325
     const bool dust_s = nbs <= kEps, dust_b = nbb <= kEps;         // :355-358
-    nbs = dust_s ? 0.0 : nbs;
-    ncs = dust_s ? 0.0 : ncs;
-    nbb = dust_b ? 0.0 : nbb;
-    ncb = dust_b ? 0.0 : ncb;
-    const double r1 = sell1 ? nbs : nbb, rc1 = sell1 ? ncs : ncb;
-    const double r2 = sell1 ? nbb : nbs, rc2 = sell1 ? ncb : ncs;
-    b1 = act ? r1 : b1;
-    c1 = act ? rc1 : c1;
-    b2 = act ? r2 : b2;
-    c2 = act ? rc2 : c2;
+    if (STRICT) {
+        nbs = dust_s ? 0.0 : nbs;
+        ncs = dust_s ? 0.0 : ncs;
+        nbb = dust_b ? 0.0 : nbb;
+        ncb = dust_b ? 0.0 : ncb;
+        const double r1 = sell1 ? nbs : nbb, rc1 = sell1 ? ncs : ncb;
+        const double r2 = sell1 ? nbb : nbs, rc2 = sell1 ? ncb : ncs;
+        b1 = act ? r1 : b1;
+        c1 = act ? rc1 : c1;
+        b2 = act ? r2 : b2;
+        c2 = act ? rc2 : c2;
+    } else {   // path form: the same selections as exec-masked moves (see withdraw)
+        if (dust_s) { asm volatile(""); nbs = 0.0; ncs = 0.0; }
+        if (dust_b) { asm volatile(""); nbb = 0.0; ncb = 0.0; }
+        if (act) {
+            asm volatile("");
+            if (sell1) { asm volatile(""); b1 = nbs; c1 = ncs; b2 = nbb; c2 = ncb; }
+            else { asm volatile(""); b1 = nbb; c1 = ncb; b2 = nbs; c2 = ncs; }
+        }
+    }
 }
 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.

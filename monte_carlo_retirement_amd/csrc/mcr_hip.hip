@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     shocks(wm + rmi, ze, zi, zp);                      // :692-693
                     market_step<ANNUAL>(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
                     if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
+                        asm volatile("");                              // keep it a branch: no lane takes it in most months
                         b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
                         yfail = true; stop = true;
                     }
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmin(need, cap);                            // :739-742 (need, cap >= 0: the max(0, .) is a no-op)
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
-                    const double prop1 = cap > kEps ? fdiv<false>(cap1, cap) : P.alloc1;  // :750-754
+                    double prop1 = fdiv<false>(cap1, cap);                            // :750-754
+                    if (!(cap > kEps)) { asm volatile(""); prop1 = P.alloc1; }        // (exec-masked move, not a select)
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
                     withdraw<false, TAXED>(b1, c1, target * prop1, L.real_rate1, gw1, nw1);  // :757-765

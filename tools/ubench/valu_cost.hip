@@ -54,6 +54,14 @@ KERNEL(cmp_lt_u32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cmp_lt_u32_
 KERNEL(cmp_eq_u64, uint64_t, seed + threadIdx.x + c, asm volatile("v_cmp_eq_u64_e64 s[20:21], %0, %1" : : "v"(x), "v"(seed) : "s20", "s21"))
 KERNEL(cmp_addc_u64, uint64_t, seed + threadIdx.x + c, { uint32_t lo32 = (uint32_t)x; asm volatile("v_cmp_lt_u64_e64 s[20:21], %1, %2\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(lo32) : "v"(x), "v"(seed) : "s20", "s21", "vcc"); x = (x & 0xFFFFFFFF00000000ull) | lo32; })
 KERNEL(cmp_addc_u32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(x) : "v"(seed) : "s20", "s21", "vcc"))
+KERNEL(cndmask_sgpr, uint32_t, seed + threadIdx.x + c, asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x) : "v"(seed)))
+KERNEL(cndmask_vcc_e32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(seed)))
+KERNEL(cndmask_vcc_e64, uint32_t, seed + threadIdx.x + c, asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x) : "v"(seed)))
+KERNEL(addc_vcc_e32, uint32_t, seed + threadIdx.x + c, asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %1, vcc" : "+v"(x) : "v"(seed)))
+KERNEL(cndmask_dpp_free, uint32_t, seed + threadIdx.x + c, asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x) : "v"(seed)))
+KERNEL(min_f64, double, seed + threadIdx.x + c, ASM2("v_min_f64"))
+KERNEL(and_b32, uint32_t, seed + threadIdx.x + c, ASM2("v_and_b32"))
+KERNEL(mov_b64, double, seed + threadIdx.x + c, asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(seed)))
 KERNEL(addc_only, uint32_t, seed + threadIdx.x + c, asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(x) : : "vcc"))
 
 template <typename T>
@@ -92,5 +100,6 @@ int main() {
     RUN(cmp_f64, double, 1.0); RUN(mov_b32, uint32_t, 3);
     RUN(cmp_lt_u64, uint64_t, 3); RUN(cmp_lt_u32, uint32_t, 3); RUN(cmp_eq_u64, uint64_t, 3);
     RUN(cmp_addc_u64, uint64_t, 3); RUN(cmp_addc_u32, uint32_t, 3); RUN(addc_only, uint32_t, 3);
+    RUN(cndmask_sgpr, uint32_t, 3); RUN(cndmask_vcc_e32, uint32_t, 3); RUN(cndmask_vcc_e64, uint32_t, 3); RUN(addc_vcc_e32, uint32_t, 3); RUN(cndmask_dpp_free, uint32_t, 3); RUN(min_f64, double, 1.5); RUN(and_b32, uint32_t, 3); RUN(mov_b64, double, 1.5);
     return 0;
 }
