@@ -59,6 +59,9 @@ KERNEL(cndmask_vcc_e32, uint32_t, seed + threadIdx.x + c, asm volatile("v_cndmas
 KERNEL(cndmask_vcc_e64, uint32_t, seed + threadIdx.x + c, asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x) : "v"(seed)))
 KERNEL(addc_vcc_e32, uint32_t, seed + threadIdx.x + c, asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %1, vcc" : "+v"(x) : "v"(seed)))
 KERNEL(cndmask_dpp_free, uint32_t, seed + threadIdx.x + c, asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x) : "v"(seed)))
+KERNEL(rcp_f32, float, seed + threadIdx.x + c, ASM1("v_rcp_f32"))
+KERNEL(cvt_f32_f64, double, seed + threadIdx.x + c, asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(*(float*)&x) : "v"(seed)))
+KERNEL(cvt_f64_f32, double, seed + threadIdx.x + c, asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x) : "v"((float)threadIdx.x)))
 KERNEL(min_f64, double, seed + threadIdx.x + c, ASM2("v_min_f64"))
 KERNEL(and_b32, uint32_t, seed + threadIdx.x + c, ASM2("v_and_b32"))
 KERNEL(mov_b64, double, seed + threadIdx.x + c, asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(seed)))
@@ -100,6 +103,6 @@ int main() {
     RUN(cmp_f64, double, 1.0); RUN(mov_b32, uint32_t, 3);
     RUN(cmp_lt_u64, uint64_t, 3); RUN(cmp_lt_u32, uint32_t, 3); RUN(cmp_eq_u64, uint64_t, 3);
     RUN(cmp_addc_u64, uint64_t, 3); RUN(cmp_addc_u32, uint32_t, 3); RUN(addc_only, uint32_t, 3);
-    RUN(cndmask_sgpr, uint32_t, 3); RUN(cndmask_vcc_e32, uint32_t, 3); RUN(cndmask_vcc_e64, uint32_t, 3); RUN(addc_vcc_e32, uint32_t, 3); RUN(cndmask_dpp_free, uint32_t, 3); RUN(min_f64, double, 1.5); RUN(and_b32, uint32_t, 3); RUN(mov_b64, double, 1.5);
+    RUN(cndmask_sgpr, uint32_t, 3); RUN(cndmask_vcc_e32, uint32_t, 3); RUN(cndmask_vcc_e64, uint32_t, 3); RUN(addc_vcc_e32, uint32_t, 3); RUN(cndmask_dpp_free, uint32_t, 3); RUN(rcp_f32, float, 1.5f); RUN(cvt_f32_f64, double, 1.5); RUN(cvt_f64_f32, double, 1.5); RUN(min_f64, double, 1.5); RUN(and_b32, uint32_t, 3); RUN(mov_b64, double, 1.5);
     return 0;
 }
