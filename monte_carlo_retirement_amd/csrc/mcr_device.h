@@ -169,7 +169,7 @@ __device__ __forceinline__ double net_liquidation_value(double bal, double cb, d
     return v;
 }
 
-// _calculate_withdrawal_and_update (:201-254), branch-free.
+// _calculate_withdrawal_and_update (:201-254): every lane evaluates the arithmetic; only the final selections differ by form.
 template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
                                          double& gross_out, double& net_out) {
@@ -214,7 +214,7 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
     }
 }
 
-// _rebalance_portfolio (:274-359), branch-free: the over-weight asset is the seller.
+// _rebalance_portfolio (:274-359): every lane evaluates the arithmetic with the over-weight asset as the seller.
 template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, double& c1, double& b2,
                                           double& c2) {
