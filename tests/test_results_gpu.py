@@ -136,3 +136,22 @@ def test_compact_document_at_a_million_paths():
     assert doc["ruin_histogram"]["failure_count"] == 1_000_000 - hb["successful_paths"]
     assert len(json.dumps(doc)) < 200_000                                  # the document stays small
     assert s["median_final_balance_successful"] >= s["final_balance_percentiles"]["p50"]
+
+
+def test_compact_document_on_the_bracketed_quantile_route():
+    """2.2 million paths (rows above the 2^21 threshold): the summary statistics and the bands of the compact document
+    come from the sample-bracketed single-pass select, and still equal pandas on the per-path frame exactly."""
+    case = CASES[1]                                   # the failing scenario: NaN-masked cohorts are non-trivial
+    n = 2_200_000
+    cfg = Config(**dict(case["cfg"], num_simulations_main=n))
+    wm = case["final_args"][0]
+    a = RetirementMonteCarloSimulator(cfg)
+    a.use_final_seeds()
+    full = R.assemble_result(cfg, wm, a.run_monte_carlo_simulations(wm, n), None)
+    b = RetirementMonteCarloSimulator(cfg)
+    b.use_final_seeds()
+    compact = R.compact_result(cfg, b, wm, None)
+    assert A.last_fallback_rows() >= 0                # the bracketed route was taken for the last select
+    for key in ("summary", "trajectory", "trajectory_real", "withdrawal_rate", "reference_lines"):
+        assert json.dumps(compact[key], allow_nan=True) == json.dumps(full[key], allow_nan=True), key
+    assert compact["ruin_histogram"]["failure_count"] == full["ruin_histogram"]["failure_count"]
