@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: paths/sec of the per-path Monte Carlo kernel (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts its own N ranks, one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same ranks, outer launcher)
 
 A "step" is one pass of the hot path over one batch of synthetic paths: ONE launch of the path
 kernel over `--paths` (default 1e6) paths per GPU of the `config.json` scenario at
@@ -117,6 +117,88 @@ def aux_hbm_kernels(torch, n):
     }
 
 
+def s60_block(torch, dist, world, n_total, reps=3):
+    """North-star shape (BASELINE configs[3]): S60 = config.json with initial_balance=2e6,
+    inv1 volatility 0.15, rho=0.3, wm=120 (720-month paths); success counts + 100-bin histogram of the
+    successful final balances over `n_total` paths IN TOTAL, sharded by global path range over the ranks
+    (`distributed.run_sharded_histogram`: counter/bin all-reduce + a min/max all-reduce for the range).
+    End to end per repetition: buffer allocation, summary-output kernel (49 B/path), min/max + bins,
+    collectives, result download.  Not part of `value`."""
+    from monte_carlo_retirement_amd import Config, params_from_config
+    from monte_carlo_retirement_amd import distributed as D
+
+    with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
+        cfg = Config(**dict(json.load(fh), initial_balance=2.0e6, inv1_returns_volatility=0.15,
+                            equity_inflation_correlation=0.3, seed=12345))
+    p = params_from_config(cfg)
+    times, r = [], None
+    for _ in range(reps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = D.run_sharded_histogram(p, 12345, 1, n_total, 120, n_bins=100)
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        times.append(float(dt.item()))
+        del dt
+    sec = sorted(times)[len(times) // 2]
+    c = r["counts"]
+    return {
+        "workload": f"BASELINE configs[3] / north-star shape: S60 (config.json, initial_balance=2e6, inv1 vol 0.15, rho=0.3), "
+                    f"wm=120 (720 months/path), {n_total} paths in total over {world} GPU(s), success count + 100-bin "
+                    "histogram of successful final balances",
+        "n_paths_total": n_total, "n_gpus": world, "seconds": sec, "paths_per_s": n_total / sec,
+        "success_probability": c.success / max(1, c.paths), "paths_counted": c.paths,
+        "hist_total": int(r["hist_bins"].sum()),
+        "exchange": "none (1 GPU)" if world == 1 else "all-reduce(sum) of the counter/bin vectors + all-reduce(min,max) of the histogram range",
+        "note": "end to end incl. allocation and download; median of %d repetitions, max over ranks" % reps,
+    }
+
+
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without an outer launcher: start N copies of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, as torch.distributed.run would), wait, and
+    return non-zero if any rank failed.  The parent never imports torch or touches a GPU; children are plain
+    child processes (nothing is exec'ed over a process that has initialised the GPU).  Rank 0 inherits stdout,
+    so its JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, pending, deadline = 0, set(range(n_ranks)), None
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                rc = rc or code
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                if deadline is None:
+                    deadline = time.monotonic() + 30.0  # the others are stuck in a collective: do not wait for them
+        if deadline is not None and time.monotonic() > deadline:
+            for r in pending:
+                procs[r].kill()  # exact PIDs this launcher started
+            for r in pending:
+                procs[r].wait()
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,10 +208,15 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the HBM-side kernels (trajectory write / quantiles / histogram)")
-    ap.add_argument("--aux-paths", type=int, default=4_000_000)
+    ap.add_argument("--aux-paths", type=int, default=10_000_000, help="paths of the BASELINE configs[2] block (hbm_kernels)")
+    ap.add_argument("--no-s60", action="store_true", help="skip the north-star S60 block")
+    ap.add_argument("--s60-paths", type=int, default=100_000_000, help="TOTAL paths of the BASELINE configs[3] block (s60)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-paths-per-thread", type=int, default=160_000)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # before torch is imported: the launcher never touches a GPU
 
     import torch
     import torch.distributed as dist
@@ -141,8 +228,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
@@ -150,19 +236,23 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(args.backend)
+    comm_dev = torch.device("cuda", device) if (world == 1 or args.backend == "nccl") else torch.device("cpu")
 
     with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
         cfg = Config(**dict(json.load(fh), seed=12345))
     params = params_from_config(cfg)
     n = args.paths
     batch = E.DeviceBatch(params, WORKING_MONTHS, n, want="count", device=device)
+    # The exchange step works on a COPY of the rank's running totals: all-reducing the accumulation vector in place
+    # would feed every step's global sum back into the next step's local counters.
+    exch = torch.zeros(batch.reduce_vec.shape, dtype=batch.reduce_vec.dtype, device=comm_dev)
 
     def step(i):
         # global path index: step-major, then rank (every path of the job is distinct)
-        begin = (i * world + rank) * n
-        batch.launch(12345, 1, begin)
+        batch.launch(12345, 1, (i * world + rank) * n)
         if world > 1:
-            dist.all_reduce(batch.reduce_vec)  # the path's single exchange step: counters + year bins, summed
+            exch.copy_(batch.reduce_vec, non_blocking=True)
+            dist.all_reduce(exch)  # the path's single exchange step: counters + year bins, summed
 
     def fence():
         if world > 1:
@@ -170,7 +260,6 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        batch.zero_counters()
         step(i)
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -182,15 +271,24 @@ def main():
         batch.launch(12345, 1, ((args.warmup + i) * world + rank) * n)
         ev[i][1].record()
         if world > 1:
-            dist.all_reduce(batch.reduce_vec)
+            exch.copy_(batch.reduce_vec, non_blocking=True)
+            dist.all_reduce(exch)
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # HIP events on the launch stream
-    counters = batch.counters.cpu().tolist()
+    # local running totals of the timed steps; with N ranks the last exchange holds the job's totals
+    counters = (exch if world > 1 else batch.reduce_vec)[:2].cpu().tolist()
+
+    s60 = None
+    if not args.no_s60:
+        try:
+            s60 = s60_block(torch, dist, world, args.s60_paths)
+        except Exception as exc:  # never lose the headline line to the auxiliary block
+            s60 = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         total_paths = n * world * args.steps
@@ -219,7 +317,8 @@ def main():
                             f"{n} paths per GPU per step, success-count only (no trajectory writeback)",
                 "paths_per_gpu_per_step": n,
                 "rng": "Philox4x32-10 + Box-Muller, counter=(path,month,stream), key=seed",
-                "parallelism": f"path-range sharding x{world}" + (" + 1 all-reduce(sum) of the counter/bin vector per step" if world > 1 else ""),
+                "parallelism": f"path-range sharding x{world}" + (
+                    f" + 1 all-reduce(sum) of the {exch.numel()}-word counter/bin vector per step ({args.backend})" if world > 1 else ""),
             },
             "roofline": {
                 "kernel": "mcr::path_kernel<0, 0, true, false>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
@@ -235,7 +334,10 @@ def main():
                         "issue (SURVEY 8d). peak = 78.6 TFLOP/s spec / 2 (the path has no FMAs: 1 op = 1 flop)",
             },
             "success_probability": counters[0] / max(1, counters[1]),
+            "paths_counted": counters[1],
         }
+        if s60 is not None:
+            out["s60"] = s60
         if not args.no_aux and world == 1:
             out["hbm_kernels"] = aux_hbm_kernels(torch, args.aux_paths)
         if not args.no_cpu_baseline and world == 1:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCR_ABI_VERSION 3
+#define MCR_ABI_VERSION 4
 #define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
 #define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */
@@ -158,6 +158,13 @@ const char* mcr_last_error(void);
 /* Shapes for (params, working_months).  Returns MCR_ERR_INVALID_ARG for working_months<0,
  * retirement_years<=0, n_streams out of range. */
 int mcr_query_sizes(const mcr_params* p, int32_t working_months, mcr_sizes* out);
+/* Range check of a parameter block — what the reference's pydantic Config enforces (backend/config.py:56-99)
+ * and the kernel relies on: amounts finite and >= 0, rates / allocation / stream tax rates in [0, 1], rho in
+ * [-1, 1], finite log-parameters with sigma >= 0 and |mu|/12 + 40 sigma/sqrt(12) < 700 (domain of the kernel's
+ * exp), n_streams in [0, MCR_MAX_STREAMS].  Every compute entry point applies it and returns
+ * MCR_ERR_INVALID_ARG (message via mcr_last_error) instead of computing with out-of-range inputs.  Not
+ * checkable up front: balances are assumed to stay within 1e-6 .. 1e15 (unscaled fp64 division). */
+int mcr_validate_params(const mcr_params* p);
 /* stream_payment_start_month_index (simulation.py:47-63). */
 int32_t mcr_stream_start_month_index(double current_age, int32_t working_months, double start_at_age);
 
@@ -182,8 +189,14 @@ int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id,
                   const double* injected_shocks, const mcr_outputs* out,
                   int device, void* hip_stream);
 
-/* Same, with HOST buffers in `out` / `injected_shocks`: allocates device scratch, runs,
- * copies back, synchronises.  Convenience for small batches and non-torch callers. */
+/* Same, with HOST buffers in `out` / `injected_shocks` (the entry point for non-torch callers, e.g. a ctypes
+ * binding inside the reference's run_monte_carlo_simulations, simulation.py:952-1010): device buffers are carved
+ * from a scratch block cached per (calling thread, device), uploads / kernel / downloads run on that thread's
+ * private non-blocking stream, and the call returns after ONE synchronisation of that stream — concurrent calls
+ * from several host threads (the reference's server runs requests on executor threads, server.py:309,405)
+ * overlap on the GPU.  Scratch blocks up to 256 MiB stay cached between calls; larger ones are freed on return.
+ * device: a HIP device ordinal, or MCR_DEVICE_ALL = shard the path range over every visible device (below). */
+#define MCR_DEVICE_ALL (-2)
 int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id,
                        uint64_t path_begin, uint64_t n_paths, int32_t working_months,
                        const double* injected_shocks, const mcr_outputs* out, int device);
@@ -198,6 +211,19 @@ int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng, uint32_t str
                            const mcr_outputs* out, int device);
 int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                              int32_t n_months, double rho, double* out, int device);
+
+/*
+ * Multi-GPU form of mcr_run_batch_host_rng for callers that bind the C ABI without torch.distributed — what
+ * replaces the reference's only parallelism, Pool.starmap over independent paths (simulation.py:996-1001):
+ * the global path range is cut into contiguous shards, one per listed device (devices == NULL or
+ * n_devices <= 0: every visible device), each shard runs on its own host thread / stream / scratch, per-path
+ * outputs land in the caller's HOST arrays at the shard's columns, and the counter / bin vectors (< 2 KB) are
+ * summed on the host.  The Philox counter carries the GLOBAL path index, so the result is bit-identical to
+ * a single-device call whatever the device list.  A device may be listed more than once.
+ */
+int mcr_run_batch_multi_host_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                                 uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                                 const mcr_outputs* out, const int32_t* devices, int32_t n_devices);
 
 /*
  * Search driver support (find_minimum_working_months, simulation.py:1138-1342): success counts of

@@ -12,7 +12,7 @@ import os
 import threading
 from typing import Optional
 
-MCR_ABI_VERSION = 3
+MCR_ABI_VERSION = 4
 MCR_MAX_STREAMS = 16
 MCR_N_COUNTERS = 2
 MCR_N_STAT_ROWS = 4
@@ -23,6 +23,7 @@ MCR_STREAM_FINAL = 1
 MCR_RNG_PHILOX = 0
 MCR_RNG_NUMPY = 1
 MCR_MAX_ENTROPY_WORDS = 8
+MCR_DEVICE_ALL = -2
 
 MCR_HELPER_WITHDRAW = 0
 MCR_HELPER_NLV = 1
@@ -175,6 +176,8 @@ ABI_SYMBOLS = (
     "mcr_run_batch_host_rng",
     "mcr_draw_shocks_host_rng",
     "mcr_probe_months_rng",
+    "mcr_run_batch_multi_host_rng",
+    "mcr_validate_params",
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
@@ -239,6 +242,13 @@ def _declare(lib: C.CDLL) -> None:
         P(McrParams), P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
         C.c_void_p, P(McrOutputs), C.c_int,
     ]
+    lib.mcr_run_batch_multi_host_rng.restype = C.c_int
+    lib.mcr_run_batch_multi_host_rng.argtypes = [
+        P(McrParams), P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32,
+        C.c_void_p, P(McrOutputs), P(C.c_int32), C.c_int32,
+    ]
+    lib.mcr_validate_params.restype = C.c_int
+    lib.mcr_validate_params.argtypes = [P(McrParams)]
     lib.mcr_draw_shocks_host_rng.restype = C.c_int
     lib.mcr_draw_shocks_host_rng.argtypes = [
         P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_double, C.c_void_p, C.c_int,

@@ -884,8 +884,8 @@ int64_t mcr_row_quantiles_reduce_block(int32_t n_rows, int64_t* n_words) {
 }
 
 int mcr_row_quantiles_begin(void* scratch, int32_t n_rows, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
     rc = rq_check(scratch, n_rows, 0, 1);
     if (rc != MCR_OK) return rc;
     const RqLayout L = rq_layout(scratch, n_rows);
@@ -910,8 +910,8 @@ int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_row
 static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
                         int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax,
                         const unsigned int* row_n, const unsigned int* row_list, int n_list, int slow_cap) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
     rc = rq_check(scratch, n_rows, n_local, n_q);
     if (rc != MCR_OK) return rc;
     if (pass < 0 || pass > 7) { set_error("pass out of range"); return MCR_ERR_INVALID_ARG; }
@@ -950,8 +950,8 @@ static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, 
 static int rq_scan_step(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
                         uint64_t* counts, void* scratch, int device, void* hip_stream, int mode,
                         const unsigned int* row_list, int n_list) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
     rc = rq_check(scratch, n_rows, 0, n_q);
     if (rc != MCR_OK) return rc;
     if (!q || !out || pass < 0 || pass > 7 || n_total <= 0 || n_total >= ((int64_t)1 << 32)) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
@@ -1071,8 +1071,7 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
 }
 
 int mcr_minmax_success(const double* values, const uint8_t* success, int64_t n, double* minmax, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
     if (!values || !success || !minmax || n < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, minmax);
@@ -1084,8 +1083,7 @@ int mcr_minmax_success(const double* values, const uint8_t* success, int64_t n, 
 
 int mcr_histogram_success(const double* values, const uint8_t* success, int64_t n, const double* minmax,
                           int32_t n_bins, uint64_t* bins, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
     if (!values || !success || !minmax || !bins || n < 0 || n_bins <= 0 || n_bins > 8192) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     if (n == 0) return MCR_OK;
     hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n, 256 * 8, 2048)), dim3(256), (size_t)n_bins * sizeof(unsigned int),
@@ -1097,8 +1095,7 @@ int mcr_histogram_success(const double* values, const uint8_t* success, int64_t 
 
 int mcr_summary_stat_rows(const double* start_balance, const double* final_balance, const double* first_year_real_gross,
                           const uint8_t* success, int64_t n, double* rows, int64_t row_stride, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
     if (!start_balance || !final_balance || !first_year_real_gross || !success || !rows || n < 0 || row_stride < n) {
         set_error("bad arguments");
         return MCR_ERR_INVALID_ARG;

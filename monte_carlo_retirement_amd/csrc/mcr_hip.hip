@@ -20,6 +20,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -424,6 +426,76 @@ int use_device(int device) {
     return MCR_OK;
 }
 
+// ---- per (thread, device) context of the host-buffer entry points (mcr_host.h) ----
+HostCtx* host_ctx(int device) {
+    static thread_local std::vector<HostCtx*> pool;
+    for (HostCtx* c : pool) if (c->device == device) return c;
+    HostCtx* c = new HostCtx{device, nullptr, nullptr, 0};
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hip_fail(e, "hipStreamCreate (host context)"); delete c; return nullptr; }
+    pool.push_back(c);
+    return c;
+}
+
+hipError_t host_ctx_reserve(HostCtx* c, size_t bytes) {
+    if (bytes <= c->capacity) return hipSuccess;
+    if (c->block) { (void)hipFree(c->block); c->block = nullptr; c->capacity = 0; }
+    hipError_t e = hipMalloc(&c->block, bytes);
+    if (e == hipSuccess) c->capacity = bytes; else c->block = nullptr;
+    return e;
+}
+
+void host_ctx_release_large(HostCtx* c) {
+    if (c->capacity > kHostCtxKeepBytes) { (void)hipFree(c->block); c->block = nullptr; c->capacity = 0; }
+}
+
+// Preconditions of the path kernel (its STRICT = false forms drop clamps that are no-ops only for rates and
+// weights in [0, 1] and non-negative amounts; fexp needs |x| < 700).  The reference enforces the same ranges
+// in its pydantic Config (backend/config.py:56-99); a ctypes caller that bypasses Config gets an error here,
+// not silently different arithmetic.
+static int validate_params(const mcr_params* p) {
+    if (!p) { set_error("null params"); return MCR_ERR_INVALID_ARG; }
+    auto bad = [](const char* name, double v, const char* want) {
+        set_error("params.%s = %g: must be %s", name, v, want);
+        return MCR_ERR_INVALID_ARG;
+    };
+    auto unit = [](double v) { return v >= 0.0 && v <= 1.0; };            // false for NaN
+    auto nonneg = [](double v) { return v >= 0.0 && std::isfinite(v); };
+    if (!nonneg(p->initial_balance)) return bad("initial_balance", p->initial_balance, "finite and >= 0 (config.py:56)");
+    if (!nonneg(p->monthly_contribution)) return bad("monthly_contribution", p->monthly_contribution, "finite and >= 0 (config.py:57)");
+    if (!nonneg(p->contribution_growth_rate_annual)) return bad("contribution_growth_rate_annual", p->contribution_growth_rate_annual, "finite and >= 0 (config.py:58)");
+    if (!nonneg(p->monthly_expenses)) return bad("monthly_expenses", p->monthly_expenses, "finite and >= 0 (config.py:59)");
+    if (!std::isfinite(p->current_age)) return bad("current_age", p->current_age, "finite (config.py:62)");
+    if (!unit(p->allocation_inv1_pct)) return bad("allocation_inv1_pct", p->allocation_inv1_pct, "in [0, 1] (config.py:70)");
+    if (!unit(p->inv1_annual_tax_on_gains_rate)) return bad("inv1_annual_tax_on_gains_rate", p->inv1_annual_tax_on_gains_rate, "in [0, 1] (config.py:73)");
+    if (!unit(p->inv1_realized_gains_tax_rate)) return bad("inv1_realized_gains_tax_rate", p->inv1_realized_gains_tax_rate, "in [0, 1] (config.py:74)");
+    if (!unit(p->inv2_annual_tax_on_gains_rate)) return bad("inv2_annual_tax_on_gains_rate", p->inv2_annual_tax_on_gains_rate, "in [0, 1] (config.py:79)");
+    if (!unit(p->inv2_realized_gains_tax_rate)) return bad("inv2_realized_gains_tax_rate", p->inv2_realized_gains_tax_rate, "in [0, 1] (config.py:80)");
+    if (!(p->equity_inflation_rho >= -1.0 && p->equity_inflation_rho <= 1.0)) return bad("equity_inflation_rho", p->equity_inflation_rho, "in [-1, 1] (config.py:85)");
+    // monthly log-growth a + b z with |z| < 40 (Box-Muller of 32-bit uniforms: |z| < 6.8, rho-mix < 9.6; ziggurat tail far
+    // below 40) must stay inside fexp's domain
+    const double sq12 = std::sqrt((double)kMPY);
+    const double mu[3] = {p->inv1_mu_log, p->inf_mu_log, p->prem_mu_log}, sg[3] = {p->inv1_sigma_log, p->inf_sigma_log, p->prem_sigma_log};
+    const char* nm[3] = {"inv1", "inf", "prem"};
+    for (int i = 0; i < 3; ++i) {
+        if (!std::isfinite(mu[i]) || !std::isfinite(sg[i]) || sg[i] < 0.0 || std::fabs(mu[i]) / kMPY + 40.0 * sg[i] / sq12 >= 700.0) {
+            set_error("params.%s_mu_log / %s_sigma_log = %g / %g: need finite values, sigma >= 0 and |mu|/12 + 40 sigma/sqrt(12) < 700",
+                      nm[i], nm[i], mu[i], sg[i]);
+            return MCR_ERR_INVALID_ARG;
+        }
+    }
+    if (p->n_streams < 0 || p->n_streams > MCR_MAX_STREAMS) { set_error("n_streams %d out of range [0, %d]", p->n_streams, MCR_MAX_STREAMS); return MCR_ERR_INVALID_ARG; }
+    for (int s = 0; s < p->n_streams; ++s) {
+        const mcr_stream& st = p->streams[s];
+        if (!nonneg(st.monthly_amount_today) || !unit(st.tax_rate) || !std::isfinite(st.start_at_age)) {
+            set_error("params.streams[%d]: monthly_amount_today %g must be finite and >= 0, tax_rate %g in [0, 1], start_at_age %g finite "
+                      "(config.py:18,23,45)", s, st.monthly_amount_today, st.tax_rate, st.start_at_age);
+            return MCR_ERR_INVALID_ARG;
+        }
+    }
+    return MCR_OK;
+}
+
 static int query_sizes(const mcr_params* p, int32_t wm, mcr_sizes* s) {
     if (!p || !s) { set_error("null argument"); return MCR_ERR_INVALID_ARG; }
     if (wm < 0) { set_error("working_months must be >= 0 (got %d)", wm); return MCR_ERR_INVALID_ARG; }
@@ -459,6 +531,8 @@ static int32_t start_month_index(double current_age, int32_t wm, double start_at
 static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     mcr_sizes sz;
     int rc = query_sizes(p, wm, &sz);
+    if (rc != MCR_OK) return rc;
+    rc = validate_params(p);
     if (rc != MCR_OK) return rc;
     std::memset(d, 0, sizeof(*d));
     d->initial_balance = p->initial_balance;
@@ -626,8 +700,7 @@ static mcr_rng philox_rng(uint64_t seed) {
 int mcr_run_batch_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
                       uint64_t n_paths, int32_t working_months, const double* injected_shocks,
                       const mcr_outputs* out, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
     return launch_paths(p, rng, stream_id, path_begin, n_paths, working_months, injected_shocks, out,
                         (hipStream_t)hip_stream);
 }
@@ -658,8 +731,8 @@ ProbeFork* probe_fork(int device) {
 int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
                          uint64_t n_paths, const int32_t* working_months, int32_t n_candidates,
                          uint64_t* counts, int device, void* hip_stream) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
     if (!working_months || !counts || n_candidates < 0) { set_error("null candidates / counts"); return MCR_ERR_INVALID_ARG; }
     if (n_candidates == 0) return MCR_OK;
     // validate every candidate BEFORE enqueueing anything, so a bad one leaves no half-forked work behind
@@ -714,12 +787,12 @@ int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id, u
     return mcr_run_batch_host_rng(p, &r, stream_id, path_begin, n_paths, working_months, injected_shocks, out, device);
 }
 
-int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng_in, uint32_t stream_id, uint64_t path_begin,
-                           uint64_t n_paths, int32_t working_months, const double* injected_shocks,
-                           const mcr_outputs* out, int device) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
-    rc = check_rng(rng_in);
+// One host-buffer batch on `device`: device buffers carved from the thread's cached block, uploads / kernel /
+// downloads on the thread's private stream, ONE stream synchronisation at the end.
+static int run_batch_host_on(int device, const mcr_params* p, const mcr_rng* rng_in, uint32_t stream_id, uint64_t path_begin,
+                             uint64_t n_paths, int32_t working_months, const double* injected_shocks, const mcr_outputs* out) {
+    MCR_ENTER_DEVICE(device);
+    int rc = check_rng(rng_in);
     if (rc != MCR_OK) return rc;
     mcr_sizes sz;
     rc = query_sizes(p, working_months, &sz);
@@ -729,22 +802,20 @@ int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng_in, uint32_t 
     const int64_t hstride = out->path_stride > 0 ? out->path_stride : (int64_t)n_paths;
     if ((uint64_t)hstride < n_paths) { set_error("path_stride < n_paths"); return MCR_ERR_INVALID_ARG; }
     const size_t n = (size_t)n_paths;
-    DeviceArena arena;
     mcr_outputs d = {};
     d.path_stride = (int64_t)((n + 63) / 64 * 64);  // device rows padded to whole wavefronts
-    struct Copy { void* dev; void* host; size_t rows, row_bytes, dev_pitch, host_pitch; };
-    std::vector<Copy> copies;
-    hipError_t e = hipSuccess;
-    auto vec = [&](double* host, double** dev) {
-        if (!host || e != hipSuccess) return;
-        e = arena.alloc((void**)dev, n * sizeof(double));
-        copies.push_back({*dev, host, 1, n * sizeof(double), 0, 0});
+    // plan: every device buffer is a slice of one block (256-byte aligned)
+    struct Buf { void** dev; void* host; size_t rows, row_bytes, dev_pitch, host_pitch, offset; bool upload, download; };
+    std::vector<Buf> bufs;
+    size_t total = 0;
+    auto plan = [&](void** dev, const void* host, size_t rows, size_t row_bytes, size_t dev_pitch, size_t host_pitch, bool up, bool down) {
+        if (!host) return;
+        bufs.push_back({dev, const_cast<void*>(host), rows, row_bytes, dev_pitch, host_pitch, total, up, down});
+        total += ((rows == 1 ? row_bytes : rows * dev_pitch) + 255) & ~(size_t)255;
     };
+    auto vec = [&](double* host, double** dev) { plan((void**)dev, host, 1, n * sizeof(double), 0, 0, false, true); };
     auto mat = [&](double* host, double** dev, int rows) {
-        if (!host || e != hipSuccess) return;
-        e = arena.alloc((void**)dev, (size_t)rows * (size_t)d.path_stride * sizeof(double));
-        copies.push_back({*dev, host, (size_t)rows, n * sizeof(double),
-                          (size_t)d.path_stride * sizeof(double), (size_t)hstride * sizeof(double)});
+        plan((void**)dev, host, (size_t)rows, n * sizeof(double), (size_t)d.path_stride * sizeof(double), (size_t)hstride * sizeof(double), false, true);
     };
     vec(out->start_balance, &d.start_balance);
     vec(out->final_balance, &d.final_balance);
@@ -752,48 +823,129 @@ int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng_in, uint32_t 
     vec(out->first_year_gross_withdrawal, &d.first_year_gross_withdrawal);
     vec(out->first_year_real_gross_withdrawal, &d.first_year_real_gross_withdrawal);
     vec(out->inflation_at_retirement, &d.inflation_at_retirement);
-    if (out->success && e == hipSuccess) {
-        e = arena.alloc((void**)&d.success, n);
-        copies.push_back({d.success, out->success, 1, n, 0, 0});
-    }
+    plan((void**)&d.success, out->success, 1, n, 0, 0, false, true);
     mat(out->trajectory, &d.trajectory, sz.trajectory_len);
     mat(out->real_trajectory, &d.real_trajectory, sz.trajectory_len);
     mat(out->withdrawal_rate_trajectory, &d.withdrawal_rate_trajectory, sz.retirement_years);
-    // accumulated counters: seed the device copy with the caller's current values
-    auto acc = [&](uint64_t* host, uint64_t** dev, size_t count) {
-        if (!host || e != hipSuccess) return;
-        e = arena.alloc((void**)dev, count * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemcpy(*dev, host, count * sizeof(uint64_t), hipMemcpyHostToDevice);
-        copies.push_back({*dev, host, 1, count * sizeof(uint64_t), 0, 0});
-    };
-    acc(out->counters, &d.counters, MCR_N_COUNTERS);
-    acc(out->wr_obs_counts, &d.wr_obs_counts, (size_t)sz.retirement_years);
-    acc(out->ruin_year_bins, &d.ruin_year_bins, (size_t)sz.ruin_bins);
+    // accumulated counters: the device copy starts from the caller's current values
+    plan((void**)&d.counters, out->counters, 1, MCR_N_COUNTERS * sizeof(uint64_t), 0, 0, true, true);
+    plan((void**)&d.wr_obs_counts, out->wr_obs_counts, 1, (size_t)sz.retirement_years * sizeof(uint64_t), 0, 0, true, true);
+    plan((void**)&d.ruin_year_bins, out->ruin_year_bins, 1, (size_t)sz.ruin_bins * sizeof(uint64_t), 0, 0, true, true);
     double* d_inj = nullptr;
-    if (injected_shocks && e == hipSuccess) {
-        const size_t bytes = n * (size_t)sz.shock_rows * 3 * sizeof(double);
-        e = arena.alloc((void**)&d_inj, bytes);
-        if (e == hipSuccess) e = hipMemcpy(d_inj, injected_shocks, bytes, hipMemcpyHostToDevice);
-    }
+    plan((void**)&d_inj, injected_shocks, 1, n * (size_t)sz.shock_rows * 3 * sizeof(double), 0, 0, true, false);
     mcr_rng rng = *rng_in;
-    if (rng.path_seeds && e == hipSuccess) {  // explicit per-path seeds: upload
-        uint32_t* d_seeds = nullptr;
-        e = arena.alloc((void**)&d_seeds, n * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(d_seeds, rng.path_seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice);
-        rng.path_seeds = d_seeds;
+    uint32_t* d_seeds = nullptr;   // explicit per-path seeds: upload
+    plan((void**)&d_seeds, rng.path_seeds, 1, n * sizeof(uint32_t), 0, 0, true, false);
+
+    HostCtx* ctx = host_ctx(device);
+    if (!ctx) return MCR_ERR_HIP;
+    hipError_t e = host_ctx_reserve(ctx, total);
+    if (e != hipSuccess) return hip_fail(e, "device allocation (host-buffer batch)");
+    for (Buf& b : bufs) {
+        *b.dev = (char*)ctx->block + b.offset;
+        if (b.upload && e == hipSuccess) e = hipMemcpyAsync(*b.dev, b.host, b.row_bytes, hipMemcpyHostToDevice, ctx->stream);
     }
-    if (e != hipSuccess) return hip_fail(e, "device allocation / upload");
-    rc = launch_paths(p, &rng, stream_id, path_begin, n_paths, working_months, d_inj, &d, nullptr);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return hip_fail(e, "upload"); }
+    if (rng.path_seeds) rng.path_seeds = d_seeds;
+    rc = launch_paths(p, &rng, stream_id, path_begin, n_paths, working_months, d_inj, &d, ctx->stream);
+    if (rc == MCR_OK) {
+        for (const Buf& b : bufs) {
+            if (!b.download || e != hipSuccess) continue;
+            if (b.rows == 1) e = hipMemcpyAsync(b.host, *b.dev, b.row_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            else e = hipMemcpy2DAsync(b.host, b.host_pitch, *b.dev, b.dev_pitch, b.row_bytes, b.rows, hipMemcpyDeviceToHost, ctx->stream);
+        }
+    }
+    const hipError_t es = hipStreamSynchronize(ctx->stream);   // this thread's stream only
+    host_ctx_release_large(ctx);
     if (rc != MCR_OK) return rc;
-    e = hipDeviceSynchronize();
-    if (e != hipSuccess) return hip_fail(e, "path_kernel execution");
-    for (const Copy& c : copies) {
-        if (c.rows == 1) e = hipMemcpy(c.host, c.dev, c.row_bytes, hipMemcpyDeviceToHost);
-        else e = hipMemcpy2D(c.host, c.host_pitch, c.dev, c.dev_pitch, c.row_bytes, c.rows, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return hip_fail(e, "download");
+    if (e != hipSuccess) return hip_fail(e, "download");
+    if (es != hipSuccess) return hip_fail(es, "path_kernel execution");
+    return MCR_OK;
+}
+
+// The same batch sharded over several devices: contiguous global path ranges, one host thread per device
+// (each with its own stream and scratch), counter / bin vectors summed on the host.  No collective is needed:
+// the exchange step of the path is < 2 KB and lands in host memory anyway.
+static int run_batch_host_multi(const int32_t* devices, int32_t n_devices, const mcr_params* p, const mcr_rng* rng_in,
+                                uint32_t stream_id, uint64_t path_begin, uint64_t n_paths, int32_t working_months,
+                                const double* injected_shocks, const mcr_outputs* out) {
+    if (!out || !rng_in) { set_error("null outputs / rng"); return MCR_ERR_INVALID_ARG; }
+    mcr_sizes sz;
+    int rc = query_sizes(p, working_months, &sz);
+    if (rc != MCR_OK) return rc;
+    std::vector<int> devs;
+    if (!devices || n_devices <= 0) {
+        const int n = mcr_device_count();
+        if (n <= 0) { set_error("no usable HIP device (the engine has no CPU fallback)"); return MCR_ERR_NO_DEVICE; }
+        for (int i = 0; i < n; ++i) devs.push_back(i);
+    } else {
+        devs.assign(devices, devices + n_devices);
+    }
+    const size_t W = devs.size();
+    if (W == 1) return run_batch_host_on(devs[0], p, rng_in, stream_id, path_begin, n_paths, working_months, injected_shocks, out);
+    const int64_t hstride = out->path_stride > 0 ? out->path_stride : (int64_t)n_paths;
+    const uint64_t per = (n_paths + W - 1) / W;
+    struct Shard {
+        int rc = MCR_OK;
+        char err[512] = "";
+        std::vector<uint64_t> counters, wr, ruin;
+    };
+    std::vector<Shard> shards(W);
+    std::vector<std::thread> threads;
+    for (size_t w = 0; w < W; ++w) {
+        const uint64_t begin = std::min<uint64_t>(w * per, n_paths);
+        const uint64_t count = std::min<uint64_t>(per, n_paths - begin);
+        if (count == 0) continue;
+        Shard& S = shards[w];
+        S.counters.assign(MCR_N_COUNTERS, 0);
+        S.wr.assign((size_t)sz.retirement_years, 0);
+        S.ruin.assign((size_t)sz.ruin_bins, 0);
+        threads.emplace_back([&, w, begin, count]() {
+            Shard& T = shards[w];
+            mcr_outputs o = *out;    // host pointers of this shard's columns
+            auto shift = [&](double*& ptr) { if (ptr) ptr += begin; };
+            shift(o.start_balance); shift(o.final_balance); shift(o.years_to_ruin);
+            shift(o.first_year_gross_withdrawal); shift(o.first_year_real_gross_withdrawal); shift(o.inflation_at_retirement);
+            if (o.success) o.success += begin;
+            shift(o.trajectory); shift(o.real_trajectory); shift(o.withdrawal_rate_trajectory);
+            o.path_stride = hstride;
+            o.counters = out->counters ? T.counters.data() : nullptr;
+            o.wr_obs_counts = out->wr_obs_counts ? T.wr.data() : nullptr;
+            o.ruin_year_bins = out->ruin_year_bins ? T.ruin.data() : nullptr;
+            mcr_rng r = *rng_in;
+            if (r.path_seeds) r.path_seeds += begin;
+            const double* inj = injected_shocks ? injected_shocks + (size_t)begin * (size_t)sz.shock_rows * 3u : nullptr;
+            T.rc = run_batch_host_on(devs[w], p, &r, stream_id, path_begin + begin, count, working_months, inj, &o);
+            if (T.rc != MCR_OK) std::snprintf(T.err, sizeof(T.err), "device %d: %s", devs[w], mcr_last_error());
+        });
+    }
+    for (std::thread& t : threads) t.join();
+    for (const Shard& S : shards)
+        if (S.rc != MCR_OK) { set_error("%s", S.err); return S.rc; }
+    for (const Shard& S : shards) {
+        if (S.counters.empty()) continue;
+        if (out->counters) for (int k = 0; k < MCR_N_COUNTERS; ++k) out->counters[k] += S.counters[k];
+        if (out->wr_obs_counts) for (int k = 0; k < sz.retirement_years; ++k) out->wr_obs_counts[k] += S.wr[k];
+        if (out->ruin_year_bins) for (int k = 0; k < sz.ruin_bins; ++k) out->ruin_year_bins[k] += S.ruin[k];
     }
     return MCR_OK;
 }
+
+int mcr_run_batch_host_rng(const mcr_params* p, const mcr_rng* rng_in, uint32_t stream_id, uint64_t path_begin,
+                           uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                           const mcr_outputs* out, int device) {
+    if (device == MCR_DEVICE_ALL)
+        return run_batch_host_multi(nullptr, 0, p, rng_in, stream_id, path_begin, n_paths, working_months, injected_shocks, out);
+    return run_batch_host_on(device, p, rng_in, stream_id, path_begin, n_paths, working_months, injected_shocks, out);
+}
+
+int mcr_run_batch_multi_host_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
+                                 uint64_t n_paths, int32_t working_months, const double* injected_shocks,
+                                 const mcr_outputs* out, const int32_t* devices, int32_t n_devices) {
+    return run_batch_host_multi(devices, n_devices, p, rng, stream_id, path_begin, n_paths, working_months, injected_shocks, out);
+}
+
+int mcr_validate_params(const mcr_params* p) { return validate_params(p); }
 
 int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                          int32_t n_months, double rho, double* out, int device) {
@@ -803,8 +955,8 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
 
 int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                              int32_t n_months, double rho, double* out, int device) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
     rc = check_rng(rng);
     if (rc != MCR_OK) return rc;
     const uint64_t seed = rng->philox_seed;
@@ -841,8 +993,8 @@ int mcr_draw_shocks_host_rng(const mcr_rng* rng, uint32_t stream_id, uint64_t pa
 }
 
 int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out, int64_t n, int device) {
-    int rc = use_device(device);
-    if (rc != MCR_OK) return rc;
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
     int n_in, n_out;
     switch (which) {
         case MCR_HELPER_WITHDRAW: n_in = 5; n_out = 4; break;

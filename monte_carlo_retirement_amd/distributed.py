@@ -72,6 +72,18 @@ def unpack_counts(vec: np.ndarray, retirement_years: int) -> ReducedCounts:
     return ReducedCounts(int(vec[0]), int(vec[1]), vec[2:2 + ry].copy(), vec[2 + ry:].copy())
 
 
+def broadcast_int(value: int, src: int = 0) -> int:
+    """``value`` of rank ``src`` on every rank (no-op without a process group).  Values up to 2**63 - 1."""
+    if not is_active():
+        return int(value)
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_comm_device())
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def all_reduce_sum_(tensor) -> None:
     """In-place sum over ranks (the path's single exchange step)."""
     import torch.distributed as dist

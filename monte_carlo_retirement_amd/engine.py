@@ -12,7 +12,7 @@ Two families:
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 
@@ -64,8 +64,13 @@ def run_batch_host(
     want_bins: bool = True,
     device: int = 0,
     path_seeds: Optional[np.ndarray] = None,
+    devices: Optional[Sequence[int]] = None,
 ) -> Dict[str, np.ndarray]:
     """Simulate paths [path_begin, path_begin+n_paths) on the GPU; numpy arrays out.
+
+    ``device``: HIP ordinal, or ``_native.MCR_DEVICE_ALL`` = shard over every visible device.  ``devices``: an
+    explicit device list instead (``mcr_run_batch_multi_host_rng``: one host thread per entry, contiguous shards
+    of the path range, counters summed on the host) — same numbers whatever the list.
 
     ``seed``: int (Philox key) or an ``McrRng`` (e.g. ``_native.numpy_rng(main_seed, child_offset)``);
     ``path_seeds``: explicit uint32 seed per path for the NumPy stream.
@@ -115,6 +120,14 @@ def run_batch_host(
         if seeds_arr.shape != (n,):
             raise ValueError("path_seeds must have one uint32 per path")
         rng.path_seeds = seeds_arr.ctypes.data
+    if devices is not None:
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        rc = lib.mcr_run_batch_multi_host_rng(
+            C.byref(params), C.byref(rng), int(stream_id), int(path_begin), n, int(working_months),
+            inj, C.byref(o), devs, len(devices),
+        )
+        N.check(rc, "mcr_run_batch_multi_host_rng")
+        return res
     rc = lib.mcr_run_batch_host_rng(
         C.byref(params), C.byref(rng), int(stream_id), int(path_begin), n, int(working_months),
         inj, C.byref(o), int(device),

@@ -123,24 +123,29 @@ def trajectory_time_points(working_months: int, retirement_years: int) -> List[f
 
 
 def _gather_columns(rows, picked) -> np.ndarray:
-    """``rows[:, picked].T`` as a host array, one strided column view per pick (host-side 64-bit pointer
-    arithmetic; a bad index raises IndexError here, whereas torch.index_select would assert on the device)."""
+    """``rows[:, picked].T`` as a host array.  Each pick is a strided column VIEW (``select`` is metadata only: the
+    64-bit offset is folded into the view's data pointer on the host) and the stack kernel then indexes k tensors of
+    T elements each.  No torch INDEXING kernel (``index_select`` / advanced indexing) ever sees the [2T+ry, stride]
+    slab, which exceeds 2**32 elements from ~3.2e7 paths on: the one GPU-side abort of round 1 was such a gather
+    on a 3.3e7-path slab."""
     import torch
 
     return torch.stack([rows[:, int(g)] for g in picked]).cpu().numpy()
 
 
 def _summary_frame(batch, n: int) -> pd.DataFrame:
-    """summary_df (simulation.py:1012-1027) from a device batch: ONE packed device->host transfer of the
-    six float columns through a pinned buffer (the per-path frame is the only O(n) object that has to cross
-    PCIe), then a no-copy DataFrame with the reference's column order and dtypes."""
+    """summary_df (simulation.py:1012-1027) from a device batch: the six float columns and the flags go device->host
+    as plain contiguous 1-D copies into ONE pinned [6, n] buffer (no stack / indexing kernel on the device, so the
+    element count any torch kernel sees stays n whatever the batch size), then a no-copy DataFrame with the
+    reference's column order and dtypes."""
     torch = batch.torch
     fields = list(_FIELD_OF.items())
-    packed = torch.stack([batch.summary[f][:n] for _, f in fields])            # [6, n] on the device
-    host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
-    host.copy_(packed, non_blocking=False)
+    host = torch.empty((len(fields), n), dtype=torch.float64, pin_memory=True)
+    for i, (_, f) in enumerate(fields):
+        host[i].copy_(batch.summary[f][:n], non_blocking=True)
     flags = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-    flags.copy_(batch.success[:n])
+    flags.copy_(batch.success[:n], non_blocking=True)
+    torch.cuda.current_stream(batch.success.device).synchronize()
     h = host.numpy()
     cols = {name: h[i] for i, (name, _) in enumerate(fields)}
     cols["Success"] = flags.numpy().view(np.bool_)
@@ -178,7 +183,10 @@ class RetirementMonteCarloSimulator:
         elif self.params_model.seed is not None:
             self.main_seed = self.params_model.seed
         else:
-            self.main_seed = _seed_from_timestamp()
+            # No seed configured: the reference hashes the current time (utils.py:16-18).  With one process per
+            # GPU every rank would draw its OWN seed — different Philox keys per shard, different sampled
+            # columns per rank — so rank 0's seed is broadcast and every rank uses it.
+            self.main_seed = D.broadcast_int(_seed_from_timestamp()) if D.is_active() else _seed_from_timestamp()
 
         # Two independent streams (search vs final run, :147-151): the stream id is one word of the
         # Philox counter, so the streams never overlap.
@@ -266,7 +274,7 @@ class RetirementMonteCarloSimulator:
         r = E.eval_helper_host(
             N.MCR_HELPER_WITHDRAW, None,
             [[bal_inv, cb_inv, net_withdrawal_target_for_inv, 1.0 if use_real_tax else 0.0, real_tax_rate]],
-            self.device,
+            self._local_device(),
         )[0]
         return float(r[0]), float(r[1]), float(r[2]), float(r[3])
 
@@ -277,7 +285,7 @@ class RetirementMonteCarloSimulator:
         return float(E.eval_helper_host(
             N.MCR_HELPER_NLV, None,
             [[balance, cost_basis, 1.0 if use_realized_gains_tax else 0.0, realized_gains_tax_rate]],
-            self.device,
+            self._local_device(),
         )[0][0])
 
     def _rebalance_portfolio(
@@ -285,7 +293,7 @@ class RetirementMonteCarloSimulator:
     ) -> Tuple[float, float, float, float]:
         """Tax-aware rebalance to the target allocation — simulation.py:274-359."""
         r = E.eval_helper_host(N.MCR_HELPER_REBALANCE, self._current_params(),
-                               [[bal_inv1, cb_inv1, bal_inv2, cb_inv2]], self.device)[0]
+                               [[bal_inv1, cb_inv1, bal_inv2, cb_inv2]], self._local_device())[0]
         return float(r[0]), float(r[1]), float(r[2]), float(r[3])
 
     def _apply_annual_gain_taxes(
@@ -296,13 +304,13 @@ class RetirementMonteCarloSimulator:
         r = E.eval_helper_host(
             N.MCR_HELPER_ANNUAL_TAX, self._current_params(),
             [[balance_inv1, cost_basis_inv1, balance_inv2, cost_basis_inv2, gain_inv1, gain_inv2]],
-            self.device,
+            self._local_device(),
         )[0]
         return float(r[0]), float(r[1]), float(r[2]), float(r[3]), bool(r[4])
 
     def _monthly_gross_from_shock(self, mu_log: float, sigma_log: float, z: float) -> float:
         """exp(mu/12 + sigma/sqrt(12) z) — simulation.py:468-474."""
-        return float(E.eval_helper_host(N.MCR_HELPER_MONTHLY_GROSS, None, [[mu_log, sigma_log, z]], self.device)[0][0])
+        return float(E.eval_helper_host(N.MCR_HELPER_MONTHLY_GROSS, None, [[mu_log, sigma_log, z]], self._local_device())[0][0])
 
     def _draw_shock_path(self, n_months: int, path_seed: int) -> np.ndarray:
         """Shock rows (equity, inflation, premium) of one path, shape (n_months, 3) — the engine's
@@ -310,11 +318,11 @@ class RetirementMonteCarloSimulator:
         if self.rng == "numpy":
             return E.draw_shocks_host(
                 N.numpy_rng(self.main_seed), self._stream_id, 0, 1, int(n_months), self._equity_inflation_rho,
-                self.device, path_seeds=np.array([int(path_seed)], dtype=np.uint32),
+                self._local_device(), path_seeds=np.array([int(path_seed)], dtype=np.uint32),
             )[0]
         return E.draw_shocks_host(
             self._engine_seed, self._stream_id, int(path_seed), 1, int(n_months), self._equity_inflation_rho,
-            self.device,
+            self._local_device(),
         )[0]
 
     def _current_params(self):
@@ -331,13 +339,13 @@ class RetirementMonteCarloSimulator:
         if self.rng == "numpy":
             r = E.run_batch_host(
                 self._current_params(), N.numpy_rng(self.main_seed), self._stream_id, 0, 1,
-                int(working_months), want_bins=False, device=self.device,
+                int(working_months), want_bins=False, device=self._local_device(),
                 path_seeds=np.array([int(path_seed)], dtype=np.uint32),
             )
         else:
             r = E.run_batch_host(
                 self._current_params(), self._engine_seed, self._stream_id, int(path_seed), 1,
-                int(working_months), want_bins=False, device=self.device,
+                int(working_months), want_bins=False, device=self._local_device(),
             )
         return {
             "Start Balance": float(r["start_balance"][0]),
@@ -437,8 +445,8 @@ class RetirementMonteCarloSimulator:
         local = local.to(comm)
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
-        parts = [g[:, :D.shard_range(n, r, world)[1]] for r, g in enumerate(gathered)]
-        allf = torch.cat(parts, dim=1).cpu().numpy()
+        # trimmed and joined on the HOST (64-bit NumPy indexing whatever n is)
+        allf = np.concatenate([g[:, :D.shard_range(n, r, world)[1]].cpu().numpy() for r, g in enumerate(gathered)], axis=1)
         cols = {name: allf[i] for i, name in enumerate(_FIELD_OF.keys())}
         cols["Success"] = allf[len(fields)] != 0.0
         summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
@@ -562,7 +570,9 @@ class RetirementMonteCarloSimulator:
         # the GPU concurrently / are split across ranks).  `ahead` only holds results early: months
         # are still reported one by one, in the reference's order, and a month the reference would
         # not have probed never reaches memo, the curve or the callback.
-        patched = "run_monte_carlo_simulations" in self.__dict__
+        # (replaced on the instance, by a subclass, or by patching the class attribute)
+        patched = ("run_monte_carlo_simulations" in self.__dict__
+                   or getattr(type(self), "run_monte_carlo_simulations", None) is not _ENGINE_RUN)
         ahead: Dict[int, float] = {}
         slots = 1 if patched else self._speculation_slots(n_sims)
 
@@ -678,6 +688,10 @@ class RetirementMonteCarloSimulator:
             logger.info(f"  Search complete: estimated minimum {best} months "
                         f"({best / MONTHS_PER_YEAR:.1f} yrs) with prob {best_prob:.2f}%.")
         return best, best_prob, curve
+
+
+#: the engine's own batch driver: the search takes the count-only fast path only while this is what a call reaches
+_ENGINE_RUN = RetirementMonteCarloSimulator.run_monte_carlo_simulations
 
 
 def _seed_from_timestamp() -> int:

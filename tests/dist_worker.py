@@ -39,8 +39,16 @@ def main():
     # histogram range exchange: rank-local (min, max) -> global
     mm = torch.tensor([10.0 * (rank + 1), 100.0 * (rank + 1)], dtype=torch.float64)
     D.all_reduce_minmax_(mm)
+    # no seed configured: every rank must end up with rank 0's time-derived seed (one Philox key, one set of
+    # sampled columns for the whole group)
+    from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
+
+    import time
+    time.sleep(0.01 * rank)   # different timestamps per rank
+    unseeded = RetirementMonteCarloSimulator(Config(**dict(cfg.model_dump(by_alias=True), seed=None)))
+    own = RetirementMonteCarloSimulator(Config(**dict(cfg.model_dump(by_alias=True), seed=99 + rank)))
     with open(f"{out_path}.{rank}", "w") as fh:
-        json.dump({"rank": rank, "world": world, "shards": shards, "success": red.success, "paths": red.paths,
+        json.dump({"main_seed": unseeded.main_seed, "own_seed": own.main_seed, "rank": rank, "world": world, "shards": shards, "success": red.success, "paths": red.paths,
                    "wr": red.wr_obs_counts.tolist(), "ruin": red.ruin_year_bins.tolist(),
                    "prob": red.success_probability_pct, "minmax": mm.tolist(), "active": D.is_active()}, fh)
     dist.barrier()

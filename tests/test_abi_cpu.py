@@ -55,6 +55,35 @@ def test_host_derivations_match_reference(lib):
         E.query_sizes(params_from_config(cfg), -1)
 
 
+def test_validate_params_rejects_what_the_config_would(lib):
+    """The kernel drops clamps that are no-ops only inside the Config's ranges (config.py:56-99): a caller that
+    bypasses pydantic must get MCR_ERR_INVALID_ARG, not different arithmetic.  No device is needed."""
+    cfg = Config(**load_golden("paths_injected.json")[0]["cfg"])
+    good = params_from_config(cfg)
+    assert lib.mcr_validate_params(C.byref(good)) == 0
+    for field, value in [("inv1_realized_gains_tax_rate", 1.5), ("inv2_realized_gains_tax_rate", -0.1),
+                         ("allocation_inv1_pct", 1.0000001), ("inv1_annual_tax_on_gains_rate", float("nan")),
+                         ("initial_balance", -1.0), ("monthly_expenses", float("inf")), ("monthly_contribution", -5.0),
+                         ("contribution_growth_rate_annual", -0.01), ("equity_inflation_rho", 1.2),
+                         ("inv1_sigma_log", -0.1), ("inf_mu_log", float("nan")), ("prem_sigma_log", 100.0),
+                         ("n_streams", N.MCR_MAX_STREAMS + 1), ("n_streams", -1)]:
+        bad = params_from_config(cfg)
+        setattr(bad, field, value)
+        assert lib.mcr_validate_params(C.byref(bad)) == -1, field
+        assert field.split("_mu_log")[0].split("_sigma_log")[0] in N.last_error(), (field, N.last_error())
+    bad = params_from_config(cfg)
+    assert bad.n_streams >= 1
+    bad.streams[0].tax_rate = 2.0
+    assert lib.mcr_validate_params(C.byref(bad)) == -1 and "streams[0]" in N.last_error()
+    # the compute entry points apply the same check before anything else that needs a device... or after: either
+    # way an out-of-range block never computes
+    bad = params_from_config(cfg)
+    bad.inv1_realized_gains_tax_rate = 1.5
+    o = N.McrOutputs()
+    assert lib.mcr_run_batch_host(C.byref(bad), 1, 1, 0, 8, 12, None, C.byref(o), 0) != 0
+    assert lib.mcr_validate_params(None) == -1
+
+
 def test_no_cpu_fallback(lib):
     """Without a HIP device the compute entry points must fail loudly, never compute on the CPU."""
     if lib.mcr_device_count() > 0:

@@ -71,3 +71,4 @@ def test_sharded_counts_equal_single_process(tmp_path, oracle, world, n_total):
         assert r["wr"] == whole["wr_obs_counts"].tolist() and r["ruin"] == whole["ruin_year_bins"].tolist()
         assert r["prob"] == res[0]["prob"]
         assert r["minmax"] == [10.0, 100.0 * world]
+        assert r["main_seed"] == res[0]["main_seed"] and r["own_seed"] == 99 + r["rank"]   # seed=None: rank 0's seed everywhere

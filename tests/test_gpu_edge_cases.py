@@ -130,9 +130,11 @@ def test_launch_on_a_side_stream_and_reuse_of_buffers():
 
 
 def test_concurrent_calls_from_host_threads(oracle):
-    """The entry points are re-entrant (thread-local error state, per-call device scratch): four host
-    threads simulate different seeds at once, as the reference's server does on executor threads."""
+    """The entry points are re-entrant (thread-local error state, per-thread stream and scratch): four host
+    threads simulate different seeds at once, as the reference's server does on executor threads — and their
+    kernels OVERLAP on the GPU (private non-blocking streams, no device-wide synchronisation)."""
     import threading
+    import time
 
     cfgd = load_golden("paths_injected.json")[8]["cfg"]
     p = params_from_config(Config(**cfgd))
@@ -157,6 +159,78 @@ def test_concurrent_calls_from_host_threads(oracle):
     for t in range(4):
         for k in ("success", "final_balance", "trajectory", "counters", "ruin_year_bins"):
             assert np.array_equal(got[t][k], expected[t][k], equal_nan=True), (t, k)
+
+    # overlap: a 16 384-path count-only batch of 833-month paths is one wave on a quarter of the SIMDs (~1 ms,
+    # latency-bound); four of them from four threads must take well under four times one
+    p2 = params_from_config(Config(**load_golden("paths_injected.json")[0]["cfg"]))
+    reps, n2 = 12, 16_384
+
+    def probe(t):
+        for i in range(reps):
+            r = E.run_batch_host(p2, 7 + t, 1, 0, n2, 233, want_summary=False, want_trajectories=False, want_bins=False)
+            assert int(r["counters"][1]) == n2
+
+    probe(0)   # warm-up: stream + scratch of this thread, code object
+    t0 = time.perf_counter()
+    for t in range(4):
+        probe(t)
+    serial = time.perf_counter() - t0
+    best = float("inf")
+    for _ in range(3):
+        threads = [threading.Thread(target=probe, args=(t,)) for t in range(4)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        best = min(best, time.perf_counter() - t0)
+    assert best < 0.7 * serial, (best, serial)
+
+
+def test_multi_device_host_entry_equals_single_device(oracle):
+    """mcr_run_batch_multi_host_rng (one host thread per listed device, shards of the global path range, counters
+    summed on the host) returns exactly what one device returns for the whole range — Philox counters carry the
+    global path index.  The box has one GPU: listing it several times exercises the sharding, the column offsets
+    into the caller's arrays and the host-side sums; MCR_DEVICE_ALL takes every visible device."""
+    cfgd = load_golden("paths_injected.json")[4]["cfg"]
+    p = params_from_config(Config(**cfgd))
+    n, wm = 1001, 30
+    one = E.run_batch_host(p, 4242, 1, 17, n, wm)
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 7):
+        got = E.run_batch_host(p, 4242, 1, 17, n, wm, devices=devs)
+        for k in one:
+            assert np.array_equal(got[k], one[k], equal_nan=True), (devs, k)
+    got = E.run_batch_host(p, 4242, 1, 17, n, wm, device=N.MCR_DEVICE_ALL)
+    for k in one:
+        assert np.array_equal(got[k], one[k], equal_nan=True), ("all", k)
+    # injected shocks and explicit NumPy path seeds are offset per shard
+    sz = E.query_sizes(p, wm)
+    inj = np.random.default_rng(5).standard_normal((64, sz.shock_rows, 3))
+    a = E.run_batch_host(p, 1, 1, 0, 64, wm, injected_shocks=inj)
+    b = E.run_batch_host(p, 1, 1, 0, 64, wm, injected_shocks=inj, devices=[0, 0, 0])
+    seeds = np.arange(1000, 1064, dtype=np.uint32)
+    c = E.run_batch_host(p, N.numpy_rng(12345), 1, 0, 64, wm, path_seeds=seeds)
+    d = E.run_batch_host(p, N.numpy_rng(12345), 1, 0, 64, wm, path_seeds=seeds, devices=[0, 0, 0])
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True) and np.array_equal(c[k], d[k], equal_nan=True), k
+    ref = oracle.run_batch(p, 4242, 1, 17, n, wm)
+    assert one["counters"].tolist() == ref["counters"].tolist() and np.array_equal(one["success"], ref["success"])
+    # a bad device in the list surfaces as an error of the call, with the device named
+    with pytest.raises(RuntimeError, match="device 99"):
+        E.run_batch_host(p, 4242, 1, 0, 64, wm, devices=[0, 99])
+
+
+def test_entry_points_restore_the_callers_device():
+    """An ABI call on device d leaves the calling thread's current device as it found it (advisor r1)."""
+    import torch
+
+    assert torch.cuda.current_device() == 0
+    p = params_from_config(Config(**load_golden("paths_injected.json")[0]["cfg"]))
+    E.run_batch_host(p, 1, 1, 0, 64, 12)
+    assert torch.cuda.current_device() == 0
+    with pytest.raises(RuntimeError, match="out of range"):
+        E.run_batch_host(p, 1, 1, 0, 64, 12, device=torch.cuda.device_count())
+    assert torch.cuda.current_device() == 0
 
 
 def test_very_large_batches_use_64bit_addressing(oracle):
@@ -199,3 +273,21 @@ def test_very_large_batches_use_64bit_addressing(oracle):
     # the 100-bin histogram of successful final balances accounts for every successful path
     bins, edges = A.success_histogram(b.summary["final_balance"], b.success, 100)
     assert int(bins.sum()) == int(b.counters[0].item()) and len(edges) == 101 and np.all(np.diff(edges) > 0)
+    ok_big, fin_big = int(b.counters[0].item()), fin.copy()
+    del b
+    torch.cuda.empty_cache()
+    # the drop-in class on the same > 2^32-element slab: per-path frame, bands, sampled columns — no torch
+    # indexing kernel sees the slab
+    from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
+
+    sim = RetirementMonteCarloSimulator(Config(**cfgd), main_seed_override=31337)
+    sim.use_final_seeds()
+    df, tdf, samples, wdf, rdf, rsamples, wcounts = sim.run_monte_carlo_simulations(wm, n)
+    assert len(df) == n and int(df["Success"].sum()) == ok_big
+    np.testing.assert_array_equal(df["Final Balance"].to_numpy()[picks], fin_big)
+    assert np.array_equal(tdf.to_numpy(), tq, equal_nan=True) and wcounts == wc.tolist()
+    sel = np.random.RandomState(31337).choice(n, size=5, replace=False)
+    for j, g in enumerate(sel):
+        o = oracle.run_batch(p, 31337, 1, int(g), 1, wm)
+        np.testing.assert_allclose(samples[j], o["trajectory"][:, 0], rtol=REL, atol=ABS)
+        np.testing.assert_allclose(rsamples[j], o["real_trajectory"][:, 0], rtol=REL, atol=ABS)

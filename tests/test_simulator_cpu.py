@@ -116,6 +116,32 @@ def test_search_verification_handles_non_monotone_probabilities():
     assert months == 4 and probability == pytest.approx(50.25)
 
 
+def test_search_goes_through_an_overridden_batch_driver():
+    """The reference's search always calls self.run_monte_carlo_simulations (simulation.py:1190): a subclass
+    override or a class-level patch must be honoured exactly like a per-instance replacement."""
+    from unittest import mock
+
+    calls = []
+
+    class Sub(RetirementMonteCarloSimulator):
+        def run_monte_carlo_simulations(self, working_months, num_simulations):
+            calls.append(working_months)
+            return (_fake_frame(num_simulations, num_simulations if working_months >= 37 else 0),) + (None,) * 6
+
+    sim = Sub(_base_config(target_probability=90.0, num_simulations_search=10, seed=0))
+    assert sim.find_minimum_working_months(verbose=False)[0] == 37 and len(calls) > 3
+
+    seen = []
+
+    def fake(self, working_months, num_simulations):
+        seen.append(working_months)
+        return (_fake_frame(num_simulations, num_simulations if working_months >= 14 else 0),) + (None,) * 6
+
+    with mock.patch.object(RetirementMonteCarloSimulator, "run_monte_carlo_simulations", fake):
+        sim = RetirementMonteCarloSimulator(_base_config(target_probability=90.0, num_simulations_search=10, seed=0))
+        assert sim.find_minimum_working_months(verbose=False)[0] == 14 and len(seen) > 3
+
+
 def test_search_unreachable_target_returns_minus_one():
     sim = RetirementMonteCarloSimulator(_base_config(target_probability=99.0, num_simulations_search=10, seed=0))
     sim.run_monte_carlo_simulations = lambda wm, n: (_fake_frame(n, min(n - 1, wm // 100)),) + (None,) * 6
