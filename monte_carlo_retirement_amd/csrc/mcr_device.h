@@ -110,39 +110,102 @@ struct ShockGen {      // per-lane carry between consecutive rows
     uint32_t cw0, cw1; // words 2,3 of the last Philox block (the next pair)
 };
 
-// Row `k`, given that rows 0..k-1 of this path were generated by this ShockGen in order.
-__device__ __forceinline__ void shock_row_seq(ShockGen& G, uint64_t seed, uint32_t stream_id, uint64_t path,
-                                              uint32_t k, double rho, double rho_c, const double* tab,
-                                              double& z_eq, double& z_inf, double& z_prem) {
-    const uint32_t phase = k & 3u;  // wave-uniform
+// Row `k` for k % 4 == PHASE, given that rows 0..k-1 of this path were generated by this ShockGen in order.
+// PHASE is a template parameter: which words feed which pair, whether a Philox block is drawn and what is carried
+// are then fixed at compile time — no per-row selects or carry shuffles between the four cases (the caller
+// dispatches on the wave-uniform k & 3 with scalar branches).
+//   PHASE 0: block 3t   -> A = words 0,1, B = words 2,3          row = (A.cos, A.sin, B.cos), carry B.sin
+//   PHASE 1: block 3t+1 -> A = words 0,1; words 2,3 carried      row = (carried, A.cos, A.sin)
+//   PHASE 2: block 3t+2 -> A = carried words, B = words 0,1      row = (A.cos, A.sin, B.cos), carry B.sin, words 2,3
+//   PHASE 3: no block   -> A = carried words                     row = (carried, A.cos, A.sin)
+template <int PHASE>
+__device__ __forceinline__ void shock_row_phase(ShockGen& G, uint64_t seed, uint32_t stream_id, uint64_t path,
+                                                uint32_t k, double rho, double rho_c, const double* tab,
+                                                double& z_eq, double& z_inf, double& z_prem) {
     uint32_t x[4] = {0u, 0u, 0u, 0u};
-    if (phase != 3u)
-        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * (k >> 2) + phase, stream_id, (uint32_t)seed,
+    if (PHASE != 3)
+        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * (k >> 2) + (uint32_t)PHASE, stream_id, (uint32_t)seed,
                       (uint32_t)(seed >> 32), x);
-    // pair A: phases 0,1 -> words 0,1 of the new block; phases 2,3 -> the carried words
-    const uint32_t ar = phase < 2u ? x[0] : G.cw0, aa = phase < 2u ? x[1] : G.cw1;
+    const uint32_t ar = PHASE < 2 ? x[0] : G.cw0, aa = PHASE < 2 ? x[1] : G.cw1;
     double ac, as;
     bm_pair(ar, aa, tab, ac, as);
     double n0, n1, n2;
-    if ((phase & 1u) == 0u) {  // rows 4t, 4t+2: (A.cos, A.sin, B.cos), B.sin carried
-        const uint32_t br = phase == 0u ? x[2] : x[0], ba = phase == 0u ? x[3] : x[1];
+    if ((PHASE & 1) == 0) {
+        const uint32_t br = PHASE == 0 ? x[2] : x[0], ba = PHASE == 0 ? x[3] : x[1];
         double bc, bs;
         bm_pair(br, ba, tab, bc, bs);
         n0 = ac; n1 = as; n2 = bc;
         G.carry_z = bs;
-    } else {                   // rows 4t+1, 4t+3: (carried, A.cos, A.sin)
+    } else {
         n0 = G.carry_z; n1 = ac; n2 = as;
     }
-    if (phase == 1u || phase == 2u) { G.cw0 = x[2]; G.cw1 = x[3]; }
+    if (PHASE == 1 || PHASE == 2) { G.cw0 = x[2]; G.cw1 = x[3]; }
     z_eq = n0;
     z_inf = rho * n0 + rho_c * n1;
     z_prem = n2;
+}
+
+// Row `k`, given that rows 0..k-1 of this path were generated by this ShockGen in order (k is wave-uniform).
+__device__ __forceinline__ void shock_row_seq(ShockGen& G, uint64_t seed, uint32_t stream_id, uint64_t path,
+                                              uint32_t k, double rho, double rho_c, const double* tab,
+                                              double& z_eq, double& z_inf, double& z_prem) {
+    switch (__builtin_amdgcn_readfirstlane((int)(k & 3u))) {
+        case 0: shock_row_phase<0>(G, seed, stream_id, path, k, rho, rho_c, tab, z_eq, z_inf, z_prem); break;
+        case 1: shock_row_phase<1>(G, seed, stream_id, path, k, rho, rho_c, tab, z_eq, z_inf, z_prem); break;
+        case 2: shock_row_phase<2>(G, seed, stream_id, path, k, rho, rho_c, tab, z_eq, z_inf, z_prem); break;
+        default: shock_row_phase<3>(G, seed, stream_id, path, k, rho, rho_c, tab, z_eq, z_inf, z_prem); break;
+    }
 }
 
 // _monthly_gross_from_shock (:468-474) with a = mu_log/12 and b = sigma_log/sqrt(12) precomputed.
 __device__ __forceinline__ double monthly_gross(double a, double b, double z, const double* tab) {
     return fexp(a + b * z, tab);
 }
+
+// TWO consecutive months at once.  Rows 4t .. 4t+3 of a path use exactly Philox blocks 3t .. 3t+2 -> Box-Muller
+// pairs P0 .. P5 (normals n[12t + 2i], n[12t + 2i + 1] = Pi.cos, Pi.sin), so with a PAIR of rows as the unit which
+// word feeds which pair is fixed at compile time by the half (no per-row selects, nothing shuffled between rows):
+//   HALF 0 (rows 4t, 4t+1):   blocks 3t and 3t+1;  P0 = (w0,w1), P1 = (w2,w3) of 3t, P2 = (w0,w1) of 3t+1,
+//                             words 2,3 of 3t+1 are carried;   rows = (P0.c, P0.s, P1.c), (P1.s, P2.c, P2.s)
+//   HALF 1 (rows 4t+2, 4t+3): block 3t+2;  P3 = carried words, P4 = (w0,w1), P5 = (w2,w3);
+//                             rows = (P3.c, P3.s, P4.c), (P4.s, P5.c, P5.s)
+// The path kernel calls this at every even row (wave-uniform) and stages the two months' gross factors
+// (g1, g_inflation, g2 = g_inflation * g_premium; :522-532) in the lane's own LDS column:
+// `stage[j * kBlock]`, j = 3 * (row & 1) + {0, 1, 2} (12 KB per workgroup).  The six pairs of a HALF are
+// independent straight-line work (lots of instruction-level parallelism next to the serial month bodies of
+// the other waves).  Every value is produced by the same expressions as shock_row_seq + monthly_gross.
+struct PairCarry { uint32_t w2, w3; };
+template <int HALF>
+__device__ __forceinline__ void growth_rows2(const DevParams& P, uint64_t seed, uint32_t stream_id, uint64_t path,
+                                             uint32_t t, const double* tab, double* stage, PairCarry& C) {
+    double n[6];
+    uint32_t x[4];
+    if (HALF == 0) {
+        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        bm_pair(x[0], x[1], tab, n[0], n[1]);
+        bm_pair(x[2], x[3], tab, n[2], n[3]);
+        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t + 1u, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        bm_pair(x[0], x[1], tab, n[4], n[5]);
+        C.w2 = x[2]; C.w3 = x[3];
+    } else {
+        bm_pair(C.w2, C.w3, tab, n[0], n[1]);
+        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t + 2u, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        bm_pair(x[0], x[1], tab, n[2], n[3]);
+        bm_pair(x[2], x[3], tab, n[4], n[5]);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double z_eq = n[3 * r], z_prem = n[3 * r + 2];
+        const double z_inf = P.rho * n[3 * r] + P.rho_c * n[3 * r + 1];       // :461-464
+        const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab);
+        const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab);
+        const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab);
+        stage[(3 * r + 0) * kBlock] = g1;
+        stage[(3 * r + 1) * kBlock] = ginf;
+        stage[(3 * r + 2) * kBlock] = ginf * gprem;                             // :532
+    }
+}
+constexpr int kStageDoubles = 6 * kBlock;   // 12 KB of LDS per workgroup
 
 // STRICT vs path form of the helpers.  Inside the path kernel the state obeys 0 <= balance,
 // 0 <= cost basis, 0 <= rate <= 1 and "amount sold <= amount held" by construction, which makes several
@@ -214,6 +277,63 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
     }
 }
 
+// Path form of TWO independent evaluations of the same helper (the two assets of one month): all the arithmetic of
+// both first — two independent dependency chains the scheduler can interleave —, then the exec-masked fix-ups
+// (each branch ends a basic block; placed between the two chains they would serialise them).
+template <bool TAXED>
+__device__ __forceinline__ void net_liquidation_values2(double b1, double c1, double r1, double b2, double c2, double r2,
+                                                        double& v1, double& v2) {
+    v1 = b1; v2 = b2;
+    if (TAXED) {
+        const double t1 = fmax(0.0, b1 - c1) * r1, t2 = fmax(0.0, b2 - c2) * r2;
+        v1 = b1 - t1; v2 = b2 - t2;                              // tax <= bal when cb >= 0, rate <= 1
+    }
+    if (b1 <= kEps) { asm volatile(""); v1 = 0.0; }
+    if (b2 <= kEps) { asm volatile(""); v2 = 0.0; }
+}
+
+struct WithdrawCand { double nb, ncb, gross, net; };   // (the dust / skip tests are evaluated at the fix-up: a compare there
+                                                       //  is one instruction, a flag carried across the other chain's blocks is two)
+template <bool TAXED>
+__device__ __forceinline__ WithdrawCand withdraw_arith(double bal, double cb, double net_target, double rate) {
+    WithdrawCand w;
+    const double inv_bal = recip_nr<false>(bal);
+    if (TAXED) {
+        const double gain_fraction = div_by(fmax(0.0, bal - cb), bal, inv_bal);  // :221
+        const double net_fraction = fmax(kEps, 1.0 - gain_fraction * rate);  // :222-227
+        w.gross = fmin(fdiv<false>(net_target, net_fraction), bal);      // :228-231
+    } else {
+        w.gross = fmin(net_target, bal);
+    }
+    const double fraction_sold = div_by(w.gross, bal, inv_bal);         // :233  (gross <= bal)
+    const double basis_removed = cb * fraction_sold;                    // :234  (fraction <= 1, cb >= 0)
+    w.net = w.gross;
+    if (TAXED) {
+        const double taxable_gain = fmax(0.0, w.gross - basis_removed); // :235
+        w.net = w.gross - taxable_gain * rate;                          // :236-241 (tax <= gross)
+    }
+    w.nb = bal - w.gross;                                               // :243
+    w.ncb = cb - basis_removed;                                         // :244
+    return w;
+}
+__device__ __forceinline__ void withdraw_fixup(WithdrawCand& w, double& bal, double& cb, double net_target, double& gross_out,
+                                               double& net_out) {
+    if (w.nb <= kEps) { asm volatile(""); w.nb = 0.0; w.ncb = 0.0; }                        // :245-247
+    if ((bal <= kEps) || (net_target <= 0.0)) {                                             // :218
+        asm volatile("");
+        w.nb = bal; w.ncb = cb; w.gross = 0.0; w.net = 0.0;                                 // bal, cb >= 0 already (:219)
+    }
+    bal = w.nb; cb = w.ncb; gross_out = w.gross; net_out = w.net;
+}
+template <bool TAXED>
+__device__ __forceinline__ void withdraw2(double& b1, double& c1, double t1, double r1, double& g1, double& n1,
+                                          double& b2, double& c2, double t2, double r2, double& g2, double& n2) {
+    WithdrawCand w1 = withdraw_arith<TAXED>(b1, c1, t1, r1);
+    WithdrawCand w2 = withdraw_arith<TAXED>(b2, c2, t2, r2);
+    withdraw_fixup(w1, b1, c1, t1, g1, n1);
+    withdraw_fixup(w2, b2, c2, t2, g2, n2);
+}
+
 // _rebalance_portfolio (:274-359): every lane evaluates the arithmetic with the over-weight asset as the seller.
 template <bool STRICT = true, bool TAXED = true>
 __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, double& c1, double& b2,
@@ -223,7 +343,9 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     const bool act = (total > kEps) && (fabs(drift1) > kEps);      // :290-296
     // Wave-uniform early-out: the rebalance that closes the yearly tax step runs right after the monthly
     // one, when every lane is already within eps of its target (nothing to do for the whole wave).
-    if (__ballot(act) == 0ull) return;
+    // (the two compares are balloted separately: each folds into its v_cmp, whereas a ballot of their AND can come
+    //  out as a 0/1 VGPR that is compared again)
+    if ((__builtin_amdgcn_ballot_w64(total > kEps) & __builtin_amdgcn_ballot_w64(fabs(drift1) > kEps)) == 0ull) return;
     const bool sell1 = drift1 > 0.0;                               // :298
     const double drift2 = b2 - total * P.alloc2;                   // :328
     const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;       // seller
@@ -277,6 +399,56 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
     }
 }
 
+// Path form of _rebalance_portfolio (:274-359).  Same arithmetic as rebalance<false, TAXED>; what differs is how the
+// results land.  The whole update runs under the exec mask of the lanes that act, so nothing has to be selected
+// back for the others; the buyer is not selected on the way in: the net purchase is added to BOTH assets in place
+// (:324-325 / :352-353 for whichever is the buyer) and the seller's pair is then overwritten under its own mask
+// (:322-323 / :350-351).  10 v_cndmask + 4 masked moves, against 14 + 8 for the select-in / select-out form.
+template <bool TAXED>
+__device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, double& c1, double& b2, double& c2) {
+    const double total = b1 + b2;                                  // :288
+    const double drift1 = b1 - total * P.alloc1;                   // :293-294
+    // (A wave in which no lane acts — e.g. the rebalance that closes the yearly tax step, right after the monthly
+    //  one — skips the block through the s_cbranch_execz of this branch: no separate ballot is needed.)
+    if ((total > kEps) && (fabs(drift1) > kEps)) {                 // :290-296
+        asm volatile("");
+        const bool sell1 = drift1 > 0.0;                           // :298
+        const double drift2 = b2 - total * P.alloc2;               // :328
+        const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;   // seller
+        const double drift = sell1 ? drift1 : drift2;
+        const double alloc_s = sell1 ? P.alloc1 : P.alloc2;        // the SOLD asset's own weight (:309,:337)
+        const double rate_s = sell1 ? P.real_rate1 : P.real_rate2;
+        const double inv_bs = recip_nr<false>(bs);                 // shared by the two divisions by bs
+        double gross_sale;
+        if (TAXED) {
+            const double gain_fraction = div_by(fmax(0.0, bs - cs), bs, inv_bs);  // :301 / :329
+            const double tax_per_dollar = gain_fraction * rate_s;  // :302-306
+            const double denom = fmax(kEps, 1.0 - alloc_s * tax_per_dollar);  // :307-310
+            gross_sale = fmin(bs, fdiv<false>(drift, denom));      // :311
+        } else {
+            gross_sale = fmin(bs, drift);                          // tax_per_dollar = 0, denom = 1, drift / 1 = drift
+        }
+        const double fraction_sold = div_by(gross_sale, bs, inv_bs);   // :312
+        const double basis_removed = cs * fraction_sold;           // :313 (gross_sale <= bs, cs >= 0: the min is a no-op)
+        double net_purchase = gross_sale;                          // rates 0: tax_paid = 0
+        if (TAXED) {
+            const double taxable_gain = fmax(0.0, gross_sale - basis_removed);  // :314
+            net_purchase = gross_sale - taxable_gain * rate_s;     // :315-320
+        }
+        const double nbs = bs - gross_sale;                        // :322 (>= 0)
+        const double ncs = cs - basis_removed;                     // :323 (>= 0)
+        // (locals, not the references: a store of one value to either of two addresses would be merged into a store
+        //  through a selected pointer, which pins the whole state in scratch memory)
+        double r1b = b1 + net_purchase, r1c = c1 + net_purchase;   // :324-325 for the buyer; the seller's pair is replaced below
+        double r2b = b2 + net_purchase, r2c = c2 + net_purchase;
+        if (sell1) { asm volatile(""); r1b = nbs; r1c = ncs; }
+        else { asm volatile(""); r2b = nbs; r2c = ncs; }
+        if (r1b <= kEps) { asm volatile(""); r1b = 0.0; r1c = 0.0; }  // :355-358
+        if (r2b <= kEps) { asm volatile(""); r2b = 0.0; r2c = 0.0; }
+        b1 = r1b; c1 = r1c; b2 = r2b; c2 = r2c;
+    }
+}
+
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
 // ANNUAL = false: compile-time variant for scenarios in which no asset is on the annual-gains system (annual
 // bill identically 0, :380-390): the block below and the monthly gain accumulators are dead code.
@@ -302,19 +474,15 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
             tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
         }
     }
-    rebalance<STRICT, TAXED>(L, b1, c1, b2, c2);  // :432-442 (always)
+    if (STRICT) rebalance<true, TAXED>(L, b1, c1, b2, c2);  // :432-442 (always)
+    else rebalance_path<TAXED>(L, b1, c1, b2, c2);
     return tax_failed;
 }
 
-// Market step shared by both phases (:522-538 and :695-714).
+// Market step shared by both phases (:522-538 and :695-714), given the month's gross factors.
 template <bool ANNUAL = true>
-__device__ __forceinline__ void market_step(const DevParams& P, const double* tab, double z_eq,
-                                            double z_inf, double z_prem, double& b1, double& b2,
+__device__ __forceinline__ void market_step(double g1, double ginf, double g2, double& b1, double& b2,
                                             double& gacc1, double& gacc2, double& infl) {
-    const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab);
-    const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab);
-    const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab);
-    const double g2 = ginf * gprem;   // :532
     if (ANNUAL) {                     // the accumulators only feed the annual tax bill
         gacc1 += b1 * (g1 - 1.0);     // :534
         gacc2 += b2 * (g2 - 1.0);     // :535

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <thread>
@@ -57,16 +58,24 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 
 // __launch_bounds__(256, 4): the kernel saturates the fp64 VALU with 4 waves per SIMD (measured by capping
 // residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.
-template <int MODE, int RNG, bool TAXED, bool ANNUAL>
+// INJ = true: shocks come from io.injected (the parity hook) instead of the RNG; only instantiated with MODE 2
+// (every output is null-checked), so the hot variants carry neither the injection branches nor their registers.
+template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false>
 __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, const KernelIO io) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // LDS: math tables (mcr_math.h), [numpy ziggurat tables], [n_lock_slots][kBlock] doubles (frozen
-    // nominal stream amounts), then block counters
+    // LDS: math tables (mcr_math.h), then the NumPy ziggurat tables OR (Philox stream) the [6][kBlock] stage of two
+    // months' gross factors, [n_lock_slots][kBlock] doubles (frozen nominal stream amounts), then block counters
+#ifdef MCR_K1_TIMELINE   // diagnostic build only (tools/k1_timeline.py): per-wave start / end stamps and placement
+    const unsigned long long tl_t0 = wall_clock64();
+#endif
     double* tab = reinterpret_cast<double*>(smem_raw);
     load_math_tables(tab, threadIdx.x, kBlock);
     ZigTables zig{nullptr, nullptr, nullptr};
     if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw + kMathTabBytes, threadIdx.x, kBlock);
-    double* lock_lds = reinterpret_cast<double*>(smem_raw + kMathTabBytes + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0));
+    // Philox stream: the gross factors of two months at a time, staged per lane (growth_rows2)
+    constexpr bool kStaged = RNG == (int)MCR_RNG_PHILOX && !INJ;
+    double* stage = reinterpret_cast<double*>(smem_raw + kMathTabBytes + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0)) + threadIdx.x;
+    double* lock_lds = stage - threadIdx.x + (kStaged ? kStageDoubles : 0);
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
     // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram
     const int ry = P.retirement_years;
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     const uint64_t li = valid ? local : (io.n_paths - 1);  // tail lanes shadow the last path, write nothing
     const uint64_t path = io.path_begin + li;
     const int64_t stride = io.out.path_stride;
-    const double* inj = io.injected ? io.injected + (size_t)li * 3u * (size_t)P.shock_rows : nullptr;
+    const double* inj = INJ ? io.injected + (size_t)li * 3u * (size_t)P.shock_rows : nullptr;
 
     constexpr bool kSummary = MODE >= 1;
     constexpr bool kTraj = MODE >= 2;
@@ -93,27 +102,54 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
             if (rtraj) rtraj[(int64_t)t * stride + (int64_t)li] = px > kEps ? nominal / px : 0.0;
         }
     };
-    ShockGen sgen{0.0, 0u, 0u};  // Philox stream: carry between consecutive rows
     Pcg64 gen;  // NumPy stream: one generator per path, rows are consumed strictly in order
-    if (RNG == (int)MCR_RNG_NUMPY && !inj) {
+    if (RNG == (int)MCR_RNG_NUMPY && !INJ) {
         const uint32_t s32 = io.path_seeds ? io.path_seeds[li]
                                            : np_path_seed(io.entropy, (int)io.n_entropy, io.stream_id, io.child_offset + path);
         pcg64_seed_u32(gen, s32);
     }
-    auto shocks = [&](int row, double& ze, double& zi, double& zp) {
-        if (inj) {
+    // Top of every month (wave-uniform, outside any divergent region): rows are visited in order 0, 1, 2, ... across
+    // both phases, so each pair of rows is generated exactly when its first row comes up.
+    PairCarry carry{0u, 0u};
+    // Wave priority falls as the path advances (s_setprio takes an immediate: four levels).  The SIMD arbitrates VALU
+    // issue by priority, then age; left alone, the oldest wave of a SIMD runs far ahead and the youngest is left to
+    // finish ALONE at the end of the launch, at a fraction of the SIMD's issue rate (measured with per-wave
+    // s_memrealtime stamps: waves of one 10^6-path launch took 1.2 to 3.6 ms and the drain was 3 of its 8.4 ms).
+    // With laggards served first the waves of a SIMD finish together, the bands narrowing towards the end of the
+    // path: 8.40 -> 7.98 ms at exactly 10^6 paths (profiles/r02/k1_timeline_*.txt).
+    const int prio_t1 = P.total_months / 2, prio_t2 = (P.total_months * 3) / 4, prio_t3 = (P.total_months * 9) / 10;
+    __builtin_amdgcn_s_setprio(3);
+    auto begin_month = [&](int row) {
+        if (row == prio_t1) __builtin_amdgcn_s_setprio(2);
+        else if (row == prio_t2) __builtin_amdgcn_s_setprio(1);
+        else if (row == prio_t3) __builtin_amdgcn_s_setprio(0);
+        if (kStaged && (row & 1) == 0) {
+            if ((row & 2) == 0) growth_rows2<0>(P, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+            else growth_rows2<1>(P, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+        }
+    };
+    // gross factors of month `row` (:522-532)
+    auto growth = [&](int row, double& g1, double& ginf, double& g2) {
+        if (kStaged) {
+            const double* c = stage + (size_t)(3 * (row & 1)) * kBlock;
+            g1 = c[0]; ginf = c[kBlock]; g2 = c[2 * kBlock];
+            return;
+        }
+        double ze, zi, zp;
+        if (INJ) {
             const int r = row < P.shock_rows - 1 ? row : P.shock_rows - 1;  // :692
             ze = inj[3 * r + 0]; zi = inj[3 * r + 1]; zp = inj[3 * r + 2];
-        } else if (RNG == (int)MCR_RNG_NUMPY) {
+        } else {
             const double z0 = np_standard_normal(gen, zig);  // standard_normal((n, 3)) fills row-major (:458)
             const double z1 = np_standard_normal(gen, zig);
             const double z2 = np_standard_normal(gen, zig);
             ze = z0;
             zi = P.rho * z0 + P.rho_c * z1;                  // :461-464
             zp = z2;
-        } else {
-            shock_row_seq(sgen, io.seed, io.stream_id, path, (uint32_t)row, P.rho, P.rho_c, tab, ze, zi, zp);
         }
+        g1 = monthly_gross(P.a1, P.b1, ze, tab);
+        ginf = monthly_gross(P.ainf, P.binf, zi, tab);
+        g2 = ginf * monthly_gross(P.aprem, P.bprem, zp, tab);  // :532
     };
 
     const LaneParams L = lane_params(P);
@@ -132,14 +168,18 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     // ---- accumulation (:513-579): no lane leaves this loop early ----
     const int wm = P.working_months;
     for (int m = 1; m <= wm; ++m) {
-        if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) contrib *= P.contrib_growth_factor;  // :514-517
-        double ze, zi, zp;
-        shocks(m - 1, ze, zi, zp);                                     // :519-520
-        market_step<ANNUAL>(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);   // :522-538
+        if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) {  // :514-517 (wave-uniform: a scalar branch, not a select)
+            asm volatile("");
+            contrib *= P.contrib_growth_factor;
+        }
+        begin_month(m - 1);
+        double g1, ginf, g2;
+        growth(m - 1, g1, ginf, g2);                                   // :519-532
+        market_step<ANNUAL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl); // :534-538
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance<false, TAXED>(L, b1, c1, b2, c2);                    // :549-553
+        rebalance_path<TAXED>(L, b1, c1, b2, c2);                      // :549-553
         if (m % kMPY == 0) {                                           // :557
             pre_fail |= annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
@@ -159,18 +199,21 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
     for (; year < ry; ++year) {
-        if (__ballot(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
         double tg1 = 0.0, tg2 = 0.0, treal = 0.0;  // :635-637
         bool yfail = false;                        // :638
         int fail_rmi = 0;
         for (int mi = 0; mi < kMPY; ++mi) {
             const int rmi = year * kMPY + mi;  // :641-643
+            begin_month(wm + rmi);
             if (alive && !yfail) {
+                double g1, ginf, g2;
+                if (kStaged) growth(wm + rmi, g1, ginf, g2);           // staged factors: the LDS reads are issued early
                 const double price = infl;                             // :644
                 const double expenses = P.monthly_expenses * price;    // :645-647
                 double income = 0.0;                                   // :649
                 for (int s = 0; s < P.n_streams; ++s) {                // :650 (wave-uniform)
-                    const DevStream& S = P.streams[s];
+                    const DevStream S = P.streams[s];                  // one 32-byte scalar load per stream, not five dependent ones
                     if (rmi < S.start_month || rmi >= S.end_month) continue;  // :653-658
                     double nominal;
                     if (S.indexed) {
@@ -188,9 +231,8 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     yfail = true; stop = true;
                 }
                 if (!stop) {
-                    double ze, zi, zp;
-                    shocks(wm + rmi, ze, zi, zp);                      // :692-693
-                    market_step<ANNUAL>(P, tab, ze, zi, zp, b1, b2, gacc1, gacc2, infl);  // :695-714
+                    if (!kStaged) growth(wm + rmi, g1, ginf, g2);      // :692-705 (sequential generators draw here)
+                    market_step<ANNUAL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl);  // :706-714
                     if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
                         asm volatile("");                              // keep it a branch: no lane takes it in most months
                         b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
@@ -198,8 +240,8 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     }
                 }
                 if (!stop) {
-                    const double cap1 = net_liquidation_value<false, TAXED>(b1, c1, L.real_rate1);  // :726-731
-                    const double cap2 = net_liquidation_value<false, TAXED>(b2, c2, L.real_rate2);  // :732-737
+                    double cap1, cap2;
+                    net_liquidation_values2<TAXED>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmin(need, cap);                            // :739-742 (need, cap >= 0: the max(0, .) is a no-op)
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
@@ -207,13 +249,13 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
                     if (!(cap > kEps)) { asm volatile(""); prop1 = P.alloc1; }        // (exec-masked move, not a select)
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
-                    withdraw<false, TAXED>(b1, c1, target * prop1, L.real_rate1, gw1, nw1);  // :757-765
+                    withdraw2<TAXED>(b1, c1, target * prop1, L.real_rate1, gw1, nw1,   // :757-765
+                                     b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg1 += gw1;                                                       // :766
-                    withdraw<false, TAXED>(b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg2 += gw2;                                                       // :777
                     if (kSummary) treal += fdiv<false>((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance<false, TAXED>(L, b1, c1, b2, c2);                       // :792-796
+                    rebalance_path<TAXED>(L, b1, c1, b2, c2);                         // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
                         const bool tf = annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
@@ -272,8 +314,15 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
         if (o.inflation_at_retirement) o.inflation_at_retirement[li] = infl_ret;
         if (o.success) o.success[li] = succeeded ? 1 : 0;
     }
+#ifdef MCR_K1_TIMELINE   // the stamps go to a buffer of their own (the otherwise unused path_seeds pointer of a Philox launch)
+    if (MODE == 0 && RNG == 0 && io.path_seeds && (threadIdx.x & 63) == 0) {
+        unsigned long long* tl = (unsigned long long*)io.path_seeds + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 3;
+        tl[0] = tl_t0; tl[1] = wall_clock64();
+        tl[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));  // XCC_ID | HW_ID
+    }
+#endif
     // success count: wave ballot + popcount -> LDS -> one atomic per workgroup
-    const unsigned long long ok = __ballot(valid && succeeded);
+    const unsigned long long ok = __builtin_amdgcn_ballot_w64(valid && succeeded);
     if ((threadIdx.x & 63) == 0) atomicAdd(&blk[0], (unsigned int)__popcll(ok));
     const bool want_bins = io.out.ruin_year_bins != nullptr || io.out.wr_obs_counts != nullptr;
     if (want_bins && valid) {
@@ -585,7 +634,8 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
 }
 
 static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng) {
-    return (size_t)kMathTabBytes + (numpy_rng ? (size_t)kZigLdsBytes : 0) + (size_t)d.n_lock_slots * kBlock * sizeof(double) +
+    return (size_t)kMathTabBytes + (numpy_rng ? (size_t)kZigLdsBytes : (size_t)kStageDoubles * sizeof(double)) +
+           (size_t)d.n_lock_slots * kBlock * sizeof(double) +
            (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1)) * sizeof(unsigned int);
 }
 
@@ -639,21 +689,24 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     if (lds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
-    // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?)
-#define MCR_LAUNCH(M, R, T, A) hipLaunchKernelGGL((path_kernel<M, R, T, A>), grid, block, lds, stream, d, io)
-#define MCR_LAUNCH_T(M, R)                                                                         \
+    // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
+    // shocks (parity hook) always take the full-output variant, whose every store is null-checked
+#define MCR_LAUNCH(M, R, T, A, I) hipLaunchKernelGGL((path_kernel<M, R, T, A, I>), grid, block, lds, stream, d, io)
+#define MCR_LAUNCH_T(M, R, I)                                                                      \
     do {                                                                                           \
-        if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH(M, R, true, true); else MCR_LAUNCH(M, R, true, false); } \
-        else { if (d.any_annual_tax) MCR_LAUNCH(M, R, false, true); else MCR_LAUNCH(M, R, false, false); }               \
+        if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH(M, R, true, true, I); else MCR_LAUNCH(M, R, true, false, I); } \
+        else { if (d.any_annual_tax) MCR_LAUNCH(M, R, false, true, I); else MCR_LAUNCH(M, R, false, false, I); }               \
     } while (0)
-    if (!np_rng) {
-        if (mode == 2) MCR_LAUNCH_T(2, 0);
-        else if (mode == 1) MCR_LAUNCH_T(1, 0);
-        else MCR_LAUNCH_T(0, 0);
+    if (injected) {
+        MCR_LAUNCH_T(2, 0, true);
+    } else if (!np_rng) {
+        if (mode == 2) MCR_LAUNCH_T(2, 0, false);
+        else if (mode == 1) MCR_LAUNCH_T(1, 0, false);
+        else MCR_LAUNCH_T(0, 0, false);
     } else {
-        if (mode == 2) MCR_LAUNCH_T(2, 1);
-        else if (mode == 1) MCR_LAUNCH_T(1, 1);
-        else MCR_LAUNCH_T(0, 1);
+        if (mode == 2) MCR_LAUNCH_T(2, 1, false);
+        else if (mode == 1) MCR_LAUNCH_T(1, 1, false);
+        else MCR_LAUNCH_T(0, 1, false);
     }
 #undef MCR_LAUNCH_T
 #undef MCR_LAUNCH

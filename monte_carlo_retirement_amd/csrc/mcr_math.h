@@ -57,16 +57,25 @@ template <bool FULL = true>
 __device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr<FULL>(b)); }
 
 __device__ __forceinline__ double fexp(double x, const double* tab) {
-    const double kf = __builtin_rint(x * kExpScale);
-    double r = __builtin_fma(-kf, kExpStepHi, x);      // exact: kf < 2^20 and the step's low 21 bits are zero
+    // k = rint(x 512/ln2) by the shifter trick: the sum lands on the unit grid of [2^52, 2^53), so its low word IS k
+    // (two's complement) and subtracting the shifter gives k as a double: no v_rndne / v_cvt_i32.
+    const double shifted = __builtin_fma(x, kExpScale, 6755399441055744.0);   // 1.5 * 2^52
+    const int k = (int)(uint32_t)(uint64_t)__double_as_longlong(shifted);
+    const double kf = shifted - 6755399441055744.0;
+    double r = __builtin_fma(-kf, kExpStepHi, x);      // exact: |kf| < 2^20 and the step's low 21 bits are zero
     r = __builtin_fma(-kf, kExpStepLo, r);
-    const int k = (int)kf;
     const double t = tab[kTabExp2 + (k & ((1 << kExp2Bits) - 1))];
     // e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24), |r| <= ln2/1024: the next term r^5/120 < 1.2e-18
     double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
     p = __builtin_fma(r, p, 0.5);
     p = __builtin_fma(r * r, p, r);
-    return __builtin_ldexp(__builtin_fma(t, p, t), k >> kExp2Bits);
+    // t (1 + p) 2^(k >> 9): the scale goes straight into the exponent field of the high word (v_ashr + v_lshl_add_u32,
+    // both 32-bit) instead of v_ashr + v_ldexp_f64.  Exact while the result is a normal number (|x| < 700).
+    const double v = __builtin_fma(t, p, t);
+    const uint64_t vb = (uint64_t)__double_as_longlong(v);
+    uint32_t hi;
+    asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"(k >> kExp2Bits), "v"((uint32_t)(vb >> 32)));  // (the compiler splits it in three)
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | (vb & 0xFFFFFFFFull)));
 }
 
 __device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab) {
