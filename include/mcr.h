@@ -268,18 +268,20 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
  * NaNs skipped): for each of n_rows rows of `n` doubles at rows[r*row_stride + i], writes
  * out[r*n_q + j] = quantile(q[j]) (NaN for an all-NaN row) and, if counts != NULL,
  * counts[r] = number of non-NaN entries.  rows/out/counts are DEVICE pointers; q is HOST.
- * scratch: device buffer of mcr_row_quantiles_scratch_bytes(n_rows, n_q, n) bytes (selection state,
- * digit histograms and per-row candidate buffers of n/64 + 4096 keys and n/8 + 4096 values); 0 =
+ * scratch: device buffer of mcr_row_quantiles_scratch_bytes(n_rows, n_q, n) bytes (selection state, digit and
+ * sub-bin histograms, per-row candidate buffers of n/64 + 4096 keys and n/8 + 4096 values, cell lists); 0 =
  * unsupported shape.
  *
  * mcr_row_quantiles picks the route by row length.  Short rows: the exact radix select (8 digit passes,
- * 4 of them over the slab), fully asynchronous.  Rows of >= 2^21 entries: a select on a sample (the first
- * n/32 entries) brackets every quantile, ONE pass over the slab counts the keys around the brackets and
- * compacts the few % inside them, the select finishes on those candidates; rows whose counts do not
- * prove their brackets right take the radix passes afterwards.  The result is exact on either route.  The
- * second route reads one word back from the device (how many rows need the radix passes): it synchronises
- * hip_stream ONCE per call.  mcr_row_quantiles_last_fallback_rows reports, for the calling thread's last
- * call, -1 (radix route) or the number of rows that needed the radix passes (diagnostics / tests).
+ * 4 of them over the slab), fully asynchronous.  Rows of >= 2^21 entries, SIX launches: the first 4096 entries of
+ * every row are sorted in LDS (coarse brackets); a counting pass over a sample (the first n/32 entries) and a small
+ * per-row kernel turn them into fine brackets; ONE pass over the slab counts the keys around the brackets (with
+ * sub-histograms inside them) and compacts the few % inside; two per-row kernels locate every target in one
+ * sub-bin, collect that bin's keys and select among them.  Rows whose counts do not prove their brackets right
+ * take the radix passes afterwards.  The result is exact on either route.  The second route reads one word back
+ * from the device (how many rows need the radix passes): it synchronises hip_stream ONCE per call.
+ * mcr_row_quantiles_last_fallback_rows reports, for the calling thread's last call, -1 (radix route) or the
+ * number of rows that needed the radix passes (diagnostics / tests).
  */
 int64_t mcr_row_quantiles_scratch_bytes(int32_t n_rows, int32_t n_q, int64_t n);
 /*

@@ -10,13 +10,16 @@
 //     _QuantileMethods['linear'] / _get_indexes / _lerp), which is what DataFrame.quantile(q, axis=1)
 //     evaluates.  NaNs are skipped (the WR rows carry NaN by design, simulation.py:851,934-935).
 //     HBM-bound: each pass streams the [rows][n] slab once, 8 B/element, coalesced.
-//     Large rows avoid most of those passes (mcr_row_quantiles, single GPU): the same select runs first
-//     on a SAMPLE (the first n/32 entries) to get, per quantile, a bracket of keys that contains the
-//     wanted order statistics with overwhelming probability; ONE pass over the slab then counts the keys
-//     below / inside every bracket and compacts the few percent inside; the select finishes on those
-//     candidates with ranks shifted by the counts.  Exactness never depends on the sample: a row whose
-//     counts show a target outside its bracket (or whose candidates overflow: giant ties) simply takes
-//     the full radix passes.  Traffic: ~1.5 reads of the slab instead of 4.
+//     Large rows avoid most of those passes (mcr_row_quantiles, single GPU), in FIVE launches: (1) the first 4096
+//     entries of every row are sorted in LDS -> coarse key brackets around every quantile; (2) a counting pass over
+//     a SAMPLE (the first n/32 entries) tallies the keys below / inside every coarse bracket, with a 1024-bin
+//     sub-histogram inside each; (3) from those counts, a fine bracket per quantile that contains the wanted
+//     order statistics of the WHOLE row with overwhelming probability; (4) ONE pass over the slab counts the keys
+//     below / inside every fine bracket (again with sub-histograms) and compacts the few percent inside;
+//     (5) per row, the counts locate every target in one sub-bin ("cell", a few hundred keys), the candidates of
+//     the wanted cells are collected in LDS and selected there, and the quantiles are interpolated.  Exactness
+//     never depends on the samples: a row whose counts show a target outside its bracket (or whose candidates
+//     overflow: giant ties) simply takes the full radix passes.  Traffic: ~1.1 reads of the slab instead of 4.
 // K2  cohort min/max + np.histogram-style equal-width bins over the successful cohort.
 #include <hip/hip_runtime.h>
 
@@ -45,13 +48,8 @@ struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
     unsigned int cand_count;             // keys appended to the (rank-local) candidate buffer in pass 3
     unsigned int const_row;              // 1: every non-NaN entry of the row is the same value (done after pass 0)
     unsigned long long kmin, kmax;       // min / max key of the row (pass 0; only when the shortcut is enabled)
-    unsigned int clamp_lo, clamp_hi;     // sample mode: bit j = bracket end of quantile j runs off the sample's range
 };
 
-// What the targets of a select are (rq_scan_kernel):
-constexpr int kRqQuantiles = 0;  // order statistics around (n-1)*q, interpolated and written to `out` (the plain select)
-constexpr int kRqSample = 1;     // bracket ranks around (m-1)*q in a sample of m entries; selected values stay in RqRow
-constexpr int kRqExplicit = 2;   // ranks preset by rq_resolve_kernel (candidate select); selected values stay in RqRow
 constexpr unsigned long long kRqKeyPosInf = 0xFFF0000000000000ull;   // key_of(+inf): the largest non-NaN key
 constexpr double kRqBracketSigmas = 5.0;   // half-width of a bracket in binomial standard deviations of the sample rank
 
@@ -63,10 +61,19 @@ struct RqBracket {
     unsigned long long pos_count[2 * kRqMaxQ + 1];
     unsigned long long n_nan;
     int interval_of_q[kRqMaxQ];
+    int shift[kRqMaxQ];                            // sub-bin of a key inside interval b: (key - lo[b]) >> shift[b], or, if < 0,
+    double xlo[kRqMaxQ], inv_w[kRqMaxQ];           //   min(bins - 1, (int)((x - xlo[b]) * inv_w[b])): equal-width bins in VALUE
     int n_intervals;
     unsigned int cand_count;                       // values appended to the row's candidate buffer
     unsigned int fallback;                         // 1: the row takes the full radix passes
+    unsigned int open_lo, open_hi;                 // coarse level: bit j = quantile j's window ran off the first sample
 };
+constexpr int kRqTiny = 4096;              // first sample: sorted in LDS by one workgroup per row
+constexpr double kRqCoarseSigmas = 7.0;    // its brackets leave room for the second sample's own 5-sigma window
+constexpr int kRqMaxSubBins = 1024;        // sub-histogram bins per interval (stride of the global histograms)
+constexpr int kRqCoarseSubBits = 10;       // sample pass: 1024 bins per coarse interval
+constexpr int kRqWaves = 16;               // waves of the per-row kernels (1024 threads)
+constexpr unsigned int kRqListCap = 12288; // keys of all wanted cells of one row (LDS of rq_select_kernel: 96 KB)
 // Scratch layout: RqRow[n_rows] | hist u32[n_rows][kRqMaxT][256] | aux u32[n_rows][2] | cand u64[n_rows][cap].
 // hist|aux is ONE dense block of 32-bit counters: a multi-GPU caller sums it across ranks after every
 // histogram step (aux[r][0] = NaN count, aux[r][1] = #ranks whose candidate buffer overflowed).
@@ -111,7 +118,6 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
                                                           int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                           unsigned int* aux, unsigned long long* cand,
                                                           unsigned int cand_cap, int only_overflowed, int track_minmax,
-                                                          const unsigned int* __restrict__ row_n,
                                                           const unsigned int* __restrict__ row_list) {
     extern __shared__ __align__(16) unsigned int lh[];  // [max groups of this call][256], sized by the host
     __shared__ unsigned long long lpref[kRqMaxT];
@@ -122,11 +128,6 @@ __global__ __launch_bounds__(kRqBlock) void rq_hist_kernel(const double* __restr
     const int row = row_list ? (int)row_list[blockIdx.y] : (int)blockIdx.y;   // a call may concern a list of rows only
     if (only_overflowed && !aux[2 * row + 1]) return;  // slow path only for rows whose candidates overflowed
     if (!FIRST && st[row].const_row) return;           // all-equal row: finished after pass 0
-    if (row_n) {                                       // ragged rows (candidate buffers): this row's own length
-        const int64_t mine = (int64_t)row_n[row];
-        n = mine < n ? mine : n;
-        if (n == 0) return;
-    }
     const int G = FIRST ? 1 : st[row].n_groups;
     for (int k = threadIdx.x; k < G * 256; k += kRqBlock) lh[k] = 0u;
     if ((int)threadIdx.x < G) lpref[threadIdx.x] = FIRST ? 0ull : st[row].prefix[threadIdx.x];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(kRqBlock) void rq_cand_hist_kernel(int pass, RqRow*
 // interpolate (NumPy `linear`) and write the quantiles.
 __global__ __launch_bounds__(kRqScanBlock) void rq_scan_kernel(int64_t n, int pass, RqRow* st, unsigned int* hist,
                                                     const RqArgs args, double* out, unsigned long long* counts,
-                                                    unsigned int* aux, int mode,
+                                                    unsigned int* aux,
                                                     const unsigned int* __restrict__ row_list) {
     __shared__ unsigned long long new_prefix[kRqMaxT], grp_prefix[kRqMaxT];
     __shared__ int grp_of[kRqMaxT], n_grp;
@@ -300,44 +301,30 @@ __global__ __launch_bounds__(kRqScanBlock) void rq_scan_kernel(int64_t n, int pa
         __syncthreads();
         for (int k = t; k < kRowWords; k += kRqScanBlock) g_state[k] = l_state[k];
     };
-    if (pass == 0 && t == 0 && mode != kRqExplicit) {
+    if (pass == 0 && t == 0) {
         const unsigned long long m = (unsigned long long)n - (unsigned long long)aux[2 * row];
         S.n_valid = m;
         if (counts) counts[row] = m;
         int nt = 0;
-        unsigned int clamp_lo = 0u, clamp_hi = 0u;
         if (m > 0) {
             for (int j = 0; j < args.n_q; ++j) {
                 // _QuantileMethods['linear'].get_virtual_index = (n - 1) * quantiles
                 const double q = args.q[j];
                 const double vi = (double)(m - 1) * q;
-                if (mode == kRqQuantiles) {
-                    double prev = floor(vi), next = prev + 1.0;          // _get_indexes
-                    if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
-                    if (vi < 0.0) { prev = 0.0; next = 0.0; }
-                    S.gamma[j] = vi - floor(vi);                          // _get_gamma (linear: unchanged)
-                    S.rank[nt] = (unsigned long long)prev; S.group_of[nt] = 0; ++nt;
-                    S.rank[nt] = (unsigned long long)next; S.group_of[nt] = 0; ++nt;
-                } else {
-                    // sample of m entries: the order statistics of the whole row around quantile q lie, with
-                    // overwhelming probability, between the sample's order statistics this far from (m-1)*q
-                    const double d = ceil(kRqBracketSigmas * sqrt((double)m * q * (1.0 - q))) + 2.0;
-                    double lo = floor(vi) - d, hi = floor(vi) + 1.0 + d;
-                    if (lo < 0.0) { lo = 0.0; clamp_lo |= 1u << j; }                      // bracket open below
-                    if (hi > (double)(m - 1)) { hi = (double)(m - 1); clamp_hi |= 1u << j; }  // bracket open above
-                    S.rank[nt] = (unsigned long long)lo; S.group_of[nt] = 0; ++nt;
-                    S.rank[nt] = (unsigned long long)hi; S.group_of[nt] = 0; ++nt;
-                }
+                double prev = floor(vi), next = prev + 1.0;          // _get_indexes
+                if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
+                if (vi < 0.0) { prev = 0.0; next = 0.0; }
+                S.gamma[j] = vi - floor(vi);                          // _get_gamma (linear: unchanged)
+                S.rank[nt] = (unsigned long long)prev; S.group_of[nt] = 0; ++nt;
+                S.rank[nt] = (unsigned long long)next; S.group_of[nt] = 0; ++nt;
             }
         }
         S.n_targets = nt;
         S.n_groups = 1;
         S.prefix[0] = 0ull;
-        S.clamp_lo = clamp_lo;
-        S.clamp_hi = clamp_hi;
         // all non-NaN entries equal (e.g. the t = 0 rows: every path starts from the same balance): every order
         // statistic is that value — finish now; later passes skip the row (only when min/max were tracked)
-        S.const_row = (mode == kRqQuantiles && m > 0 && S.kmin == S.kmax) ? 1u : 0u;
+        S.const_row = (m > 0 && S.kmin == S.kmax) ? 1u : 0u;
     }
     __syncthreads();
     if (S.const_row) {
@@ -411,7 +398,7 @@ __global__ __launch_bounds__(kRqScanBlock) void rq_scan_kernel(int64_t n, int pa
     if (pass == 7) {
         if (t < nt) S.value[t] = value_of(new_prefix[t]);
         __syncthreads();
-        if (mode == kRqQuantiles && t < args.n_q) {
+        if (t < args.n_q) {
             double r;
             if (S.n_valid == 0) {
                 r = __longlong_as_double(0x7ff8000000000000LL);  // all-NaN row -> NaN (pandas na_value)
@@ -446,28 +433,27 @@ __global__ void rq_init_kernel(RqRow* st, unsigned int* hist, int n_rows) {
 }
 
 // ---- K3, bracketed single pass -------------------------------------------------------------------
-// After the sample select (kRqSample): turn the 2 bracket keys per quantile into disjoint ascending intervals.
-__global__ void rq_bracket_prep_kernel(const RqRow* st, RqBracket* br, int n_q, int n_rows, unsigned int* fb_count) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row == 0) *fb_count = 0u;
-    if (row >= n_rows) return;
-    const RqRow& S = st[row];
-    RqBracket& B = br[row];
-    B.n_nan = 0ull; B.cand_count = 0u; B.fallback = 0u; B.n_intervals = 0;
-    for (int b = 0; b < kRqMaxQ; ++b) { B.lo[b] = ~0ull; B.hi[b] = 0ull; B.interval_of_q[b] = 0; }
-    for (int k = 0; k <= 2 * kRqMaxQ; ++k) B.pos_count[k] = 0ull;
-    if (S.n_targets != 2 * n_q) { B.fallback = 1u; return; }   // the sample had no non-NaN entry
-    unsigned long long lo[kRqMaxQ], hi[kRqMaxQ];
+// Sub-bin of a key inside an interval.  Equal steps of the order-preserving KEY are (piecewise) equal steps of
+// log |x|: the right resolution for one-signed data of any dynamic range, useless for an interval that reaches or
+// straddles zero (almost all of its key range is magnitudes nobody has).  Those intervals use equal-width bins in
+// VALUE instead.  Either map is monotone in x, which is all the counting needs.
+__device__ __forceinline__ int rq_sub_bin(unsigned long long key, double x, unsigned long long lo, int shift, double xlo, double inv_w,
+                                          int bins) {
+    if (shift >= 0) return (int)((key - lo) >> shift);
+    const int b = (int)((x - xlo) * inv_w);          // x >= xlo; the conversion saturates
+    return b < bins - 1 ? b : bins - 1;
+}
+
+// Merge the brackets [lo_j, hi_j] of n_q quantiles (closed key intervals) into disjoint ascending intervals of one
+// row and set every interval's sub-bin shift for `sub_bits`-bit sub-histograms; counters zeroed.  (One thread.)
+__device__ void rq_make_intervals(RqBracket& B, const unsigned long long* lo, const unsigned long long* hi, int n_q, int sub_bits) {
     int order[kRqMaxQ];
     for (int j = 0; j < n_q; ++j) {
-        // open ends: the whole range of non-NaN keys.  The ends are exact order statistics of the sample, so a
-        // bracket that sits inside one giant tie comes out as a ONE-KEY interval (lo == hi), which needs no candidates.
-        lo[j] = ((S.clamp_lo >> j) & 1u) ? 0ull : key_of(S.value[2 * j]);
-        hi[j] = ((S.clamp_hi >> j) & 1u) ? kRqKeyPosInf : key_of(S.value[2 * j + 1]);
         int k = j;
         while (k > 0 && lo[order[k - 1]] > lo[j]) { order[k] = order[k - 1]; --k; }   // insertion sort by lo
         order[k] = j;
     }
+    for (int b = 0; b < kRqMaxQ; ++b) { B.lo[b] = ~0ull; B.hi[b] = 0ull; B.interval_of_q[b] = 0; B.shift[b] = 0; }
     int nb = 0;
     for (int i = 0; i < n_q; ++i) {
         const int j = order[i];
@@ -479,46 +465,158 @@ __global__ void rq_bracket_prep_kernel(const RqRow* st, RqBracket* br, int n_q, 
         B.interval_of_q[j] = nb - 1;
     }
     B.n_intervals = nb;
+    for (int b = 0; b < nb; ++b) {
+        const unsigned long long span = B.hi[b] - B.lo[b];
+        const int bits = span ? 64 - __clzll((long long)span) : 0;   // (span >> shift) < 2^sub_bits
+        B.shift[b] = bits > sub_bits ? bits - sub_bits : 0;
+        B.xlo[b] = 0.0; B.inv_w[b] = 0.0;
+        if (B.lo[b] != 0ull && B.hi[b] < kRqKeyPosInf && span) {     // closed, finite at the top: may take value bins
+            const double xl = value_of(B.lo[b]), xh = value_of(B.hi[b]);
+            const double w = xh - xl;
+            if (!(xl > 0.0) && !(xh < 0.0) && w > 0.0 && w < 1.0e300 && xl > -1.0e300) {   // reaches or straddles zero
+                B.shift[b] = -1;
+                B.xlo[b] = xl;
+                B.inv_w[b] = (double)(1 << sub_bits) / w;
+            }
+        }
+    }
+    for (int k = 0; k <= 2 * kRqMaxQ; ++k) B.pos_count[k] = 0ull;
+    B.n_nan = 0ull; B.cand_count = 0u; B.fallback = 0u; B.open_lo = 0u; B.open_hi = 0u;
 }
 
-// THE pass over the slab.  Every non-NaN key is located among the row's sorted interval bounds by a branch-free
-// binary search (P-entry table in LDS: bound 2b = lo[b], bound 2b+1 = hi[b]+1, padded with ~0; position = number of
-// bounds <= key), counted in a per-thread LDS histogram laid out [position][thread] (conflict-free, plain
-// read-modify-write: no atomics), and — when its position is odd, i.e. it lies inside an interval that is a real
-// range — appended to the row's candidate buffer (staged per wave in LDS: one global reservation and a coalesced
-// copy per ~256 candidates, no workgroup barrier in the loop).
+// (1) Coarse brackets.  One workgroup per row sorts the first kRqTiny entries in LDS (bitonic, NaNs last) and takes,
+// per quantile, the sample's order statistics kRqCoarseSigmas binomial standard deviations either side of the
+// quantile's rank.  A one-key interval (lo == hi: the bracket sits inside one giant tie) stays a one-key interval
+// all the way down and needs no candidates.
+__global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict__ rows, int64_t row_stride, const RqArgs args,
+                                                      RqBracket* br1, unsigned int* hist1, unsigned int* fb_count) {
+    __shared__ unsigned long long keys[kRqTiny];
+    __shared__ unsigned long long qlo[kRqMaxQ], qhi[kRqMaxQ];
+    __shared__ unsigned int nan_n, open_lo, open_hi;
+    const int row = blockIdx.x, t = threadIdx.x;
+    if (row == 0 && t == 0) *fb_count = 0u;
+    if (t == 0) { nan_n = 0u; open_lo = 0u; open_hi = 0u; }
+    __syncthreads();
+    const double* r = rows + (int64_t)row * row_stride;
+    unsigned int my_nan = 0u;
+    // element i = e * 1024 + t lives in key[e] of thread t
+    unsigned long long key[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double x = r[e * 1024 + t];
+        const bool isnan_x = x != x;
+        key[e] = isnan_x ? ~0ull : key_of(x);        // (~0 is not the key of any non-NaN double: NaNs sort last)
+        my_nan += isnan_x ? 1u : 0u;
+    }
+    if (my_nan) atomicAdd(&nan_n, my_nan);
+    unsigned int* hrow = hist1 + (size_t)row * kRqMaxQ * kRqMaxSubBins;
+    for (int k = t; k < kRqMaxQ * kRqMaxSubBins; k += 1024) hrow[k] = 0u;
+    // Bitonic sort, ascending.  Partner of i at distance j: another register of the same thread (j >= 1024), another
+    // lane of the same wave (j < 64: a shuffle, no barrier) or a thread of another wave (through LDS, two barriers).
+    for (int k = 2; k <= kRqTiny; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 1024) {   // (constant register indices: a run-time index would push key[] into scratch)
+                auto cx = [&](unsigned long long& a, unsigned long long& b, bool up) {
+                    if ((a > b) == up) { const unsigned long long x = a; a = b; b = x; }
+                };
+                if (j == 2048) { cx(key[0], key[2], true); cx(key[1], key[3], true); }          // k = 4096: ascending
+                else { cx(key[0], key[1], true); cx(key[2], key[3], k == 4096); }               // j = 1024: k = 2048 or 4096
+            } else {
+                unsigned long long other[4];
+                if (j >= 64) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keys[e * 1024 + t] = key[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) other[e] = keys[e * 1024 + (t ^ j)];
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) other[e] = (unsigned long long)__shfl_xor((long long)key[e], j, 64);
+                }
+                const bool lower = (t & j) == 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool up = (((e * 1024 + t) & k) == 0);
+                    const unsigned long long mn = key[e] < other[e] ? key[e] : other[e], mx = key[e] < other[e] ? other[e] : key[e];
+                    key[e] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) keys[e * 1024 + t] = key[e];
+    __syncthreads();
+    RqBracket& B = br1[row];
+    const int v0 = kRqTiny - (int)nan_n;
+    if (v0 < 256) {   // hardly any non-NaN entry in the sample: no basis for brackets
+        if (t == 0) { rq_make_intervals(B, qlo, qhi, 0, kRqCoarseSubBits); B.fallback = 1u; }
+        return;
+    }
+    if (t < args.n_q) {
+        const double q = args.q[t];
+        const double vi = (double)(v0 - 1) * q;
+        const double d = ceil(kRqCoarseSigmas * sqrt((double)v0 * q * (1.0 - q))) + 2.0;
+        const double lo = floor(vi) - d, hi = floor(vi) + 1.0 + d;
+        // An end that runs off the sample stops at the sample's own minimum / maximum, NOT at the end of the key range:
+        // an interval open to key 0 or +inf would spread its sub-bins over the whole exponent range and resolve nothing.
+        // Such an end is flagged: if the second sample's window reaches beyond it (extreme quantiles), the fine bracket
+        // is opened to the end of the key range there.
+        if (lo < 0.0) atomicOr(&open_lo, 1u << t);
+        if (hi > (double)(v0 - 1)) atomicOr(&open_hi, 1u << t);
+        qlo[t] = keys[lo < 0.0 ? 0 : (int)lo];
+        qhi[t] = keys[hi > (double)(v0 - 1) ? v0 - 1 : (int)hi];
+    }
+    __syncthreads();
+    if (t == 0) { rq_make_intervals(B, qlo, qhi, args.n_q, kRqCoarseSubBits); B.open_lo = open_lo; B.open_hi = open_hi; }
+}
+
+// (2) and (4) THE counting pass, over the first `n` entries of every row (the sample, then the whole slab).  Every
+// non-NaN key is located among the row's sorted interval bounds by a branch-free binary search (P-entry table in LDS:
+// bound 2b = lo[b], bound 2b+1 = hi[b]+1, padded with ~0; position = number of bounds <= key), counted in a per-thread
+// LDS histogram laid out [position][thread] (conflict-free, no contended atomics), and — when its position is odd,
+// i.e. it lies inside an interval that is a real range — tallied in that interval's sub-histogram (LDS atomics on
+// 2^sub_bits bins: the keys of one wave scatter) and, if COMPACT, appended to the row's candidate buffer (staged per
+// wave in LDS: one global reservation and a coalesced copy per ~256 candidates, no workgroup barrier in the loop).
 // 8 B/element read, a few % written.
-template <int P>
-__global__ __launch_bounds__(kRqBlock) void rq_bracket_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
-                                                             RqBracket* br, double* cand, unsigned int cand_cap) {
+template <int P, bool COMPACT>
+__global__ __launch_bounds__(kRqBlock) void rq_count_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
+                                                           RqBracket* br, unsigned int* hist, int sub_bits, double* cand,
+                                                           unsigned int cand_cap) {
     constexpr int kWaveStage = 256;                      // candidates a wave collects in LDS before it appends them
-    __shared__ double stage[(kRqBlock / 64) * kWaveStage];
+    __shared__ double stage[COMPACT ? (kRqBlock / 64) * kWaveStage : 1];
     __shared__ unsigned long long bound[P];
+    __shared__ int shl[P / 2];
+    __shared__ double xlo_s[P / 2], invw_s[P / 2];
     __shared__ unsigned int poshist[P * kRqBlock];
     __shared__ unsigned int nan_n;
+    extern __shared__ __align__(16) unsigned int subhist[];   // [P/2][2^sub_bits]
     const int row = blockIdx.y;
     RqBracket& B = br[row];
     const int nb = B.n_intervals;
     if (B.fallback || 2 * nb >= P) return;             // (the host picks P > 2 * n_q >= 2 * nb)
+    const int bins = 1 << sub_bits;
     if (threadIdx.x < P) {
         const int b = threadIdx.x >> 1;
         bound[threadIdx.x] = b < nb ? ((threadIdx.x & 1) ? B.hi[b] + 1ull : B.lo[b]) : ~0ull;   // hi <= key(+inf): no wrap
+        if ((threadIdx.x & 1) == 0) { shl[b] = b < nb ? B.shift[b] : 0; xlo_s[b] = b < nb ? B.xlo[b] : 0.0; invw_s[b] = b < nb ? B.inv_w[b] : 0.0; }
     }
     for (int k = threadIdx.x; k < P * kRqBlock; k += kRqBlock) poshist[k] = 0u;
+    for (int k = threadIdx.x; k < nb * bins; k += kRqBlock) subhist[k] = 0u;
     if (threadIdx.x == 0) nan_n = 0u;
     unsigned int keep = 0u;                            // bit b: interval b is a real range (lo < hi): members are candidates
     for (int b = 0; b < nb; ++b) keep |= (B.lo[b] < B.hi[b]) ? (1u << b) : 0u;
     keep = (unsigned int)__builtin_amdgcn_readfirstlane((int)keep);
     __syncthreads();
     const double* r = rows + (int64_t)row * row_stride;
-    double* crow = cand + (size_t)row * cand_cap;
+    double* crow = COMPACT ? cand + (size_t)row * cand_cap : nullptr;
     const int lane = threadIdx.x & 63;
     unsigned int my_nan = 0u;
-    double* wstage = stage + (threadIdx.x >> 6) * kWaveStage;   // this wave's stage; `filled` is wave-uniform
+    double* wstage = stage + (COMPACT ? (threadIdx.x >> 6) * kWaveStage : 0);   // this wave's stage; `filled` is wave-uniform
     unsigned int filled = 0u;
     // append the wave's staged candidates to the row's buffer: one global reservation, coalesced copy
     auto flush = [&]() {
-        if (filled == 0u) return;
+        if (!COMPACT || filled == 0u) return;
         unsigned int base = 0u;
         if (lane == 0) base = atomicAdd(&B.cand_count, filled);
         base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
@@ -554,9 +652,13 @@ __global__ __launch_bounds__(kRqBlock) void rq_bracket_kernel(const double* __re
         for (int u = 0; u < K; ++u) {
             atomicAdd(&poshist[pos[u] * kRqBlock + threadIdx.x], valid[u] ? 1u : 0u);   // own slot: ds_add_u32, no conflicts
             ins[u] = valid[u] && (pos[u] & 1u) && ((keep >> (pos[u] >> 1)) & 1u);
+            if (ins[u]) {
+                const unsigned int b = pos[u] >> 1;
+                atomicAdd(&subhist[b * bins + (unsigned int)rq_sub_bin(key[u], xs[u], bound[2 * b], shl[b], xlo_s[b], invw_s[b], bins)], 1u);
+            }
             mine += ins[u] ? 1u : 0u;
         }
-        if (__ballot(mine != 0u)) {           // wave-uniform
+        if (COMPACT && __ballot(mine != 0u)) {           // wave-uniform
             unsigned int scan = mine;         // inclusive scan of the per-lane candidate counts
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -630,88 +732,372 @@ __global__ __launch_bounds__(kRqBlock) void rq_bracket_kernel(const double* __re
         if (lane == 0 && c) atomicAdd(&B.pos_count[p], (unsigned long long)c);
     }
     if (threadIdx.x == 0 && nan_n) atomicAdd(&B.n_nan, (unsigned long long)nan_n);
+    unsigned int* hrow = hist + (size_t)row * kRqMaxQ * kRqMaxSubBins;
+    for (int k = threadIdx.x; k < nb * bins; k += kRqBlock)
+        if (subhist[k]) atomicAdd(&hrow[(k >> sub_bits) * kRqMaxSubBins + (k & (bins - 1))], subhist[k]);
     flush();
 }
 
-// Per row, after the bracket pass: the true ranks (NumPy `linear`, as rq_scan_kernel computes them), checked
-// against the counts and shifted into ranks inside the candidate buffer.  A row any of whose targets lies outside
-// its interval, or whose candidates overflowed, is handed to the full radix passes.
-__global__ void rq_resolve_kernel(int64_t n, const RqArgs args, RqBracket* br, RqRow* st, unsigned int* row_n,
-                                  unsigned int* row_fallback, unsigned int* fb_list, unsigned int* fb_count,
-                                  unsigned long long* counts, unsigned int cand_cap, int n_rows) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
-    RqBracket& B = br[row];
-    RqRow& S = st[row];   // freshly initialised by rq_init_kernel
-    bool fb = B.fallback != 0u;
-    if (!fb) {
-        const unsigned long long m = (unsigned long long)n - B.n_nan;
-        S.n_valid = m;
-        if (counts) counts[row] = m;
-        unsigned long long below[kRqMaxQ], upto[kRqMaxQ], run = 0ull;   // # keys < lo[b], # keys <= hi[b]
-        for (int b = 0; b < B.n_intervals; ++b) {
-            run += B.pos_count[2 * b]; below[b] = run;
-            run += B.pos_count[2 * b + 1]; upto[b] = run;
-        }
-        unsigned long long inside_before[kRqMaxQ], total_inside = 0ull;
-        unsigned int known = 0u;   // bit j: quantile j sits in a one-key interval
-        for (int b = 0; b < B.n_intervals; ++b) {
-            inside_before[b] = total_inside;
-            if (B.lo[b] != B.hi[b]) total_inside += upto[b] - below[b];   // one-key intervals stored nothing
-        }
-        if (B.cand_count > cand_cap || total_inside != (unsigned long long)B.cand_count) fb = true;
-        int nt = 0;
-        if (!fb && m > 0) {
-            for (int j = 0; j < args.n_q; ++j) {
-                const double q = args.q[j];
-                const double vi = (double)(m - 1) * q;
-                double prev = floor(vi), next = prev + 1.0;
-                if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
-                if (vi < 0.0) { prev = 0.0; next = 0.0; }
-                S.gamma[j] = vi - floor(vi);
-                const int b = B.interval_of_q[j];
-                const bool tie = B.lo[b] == B.hi[b];   // one key: every member IS that value, none was stored
-                const unsigned long long r2[2] = {(unsigned long long)prev, (unsigned long long)next};
-                for (int e = 0; e < 2; ++e) {
-                    if (r2[e] < below[b] || r2[e] >= upto[b]) fb = true;           // outside the bracket: not provable here
-                    S.rank[nt] = tie ? 0ull : r2[e] - below[b] + inside_before[b];   // rank among the candidates
-                    S.group_of[nt] = 0;
-                    ++nt;
-                }
-                if (tie) known |= 1u << j;
-            }
-        }
-        S.n_targets = fb ? 0 : nt;
-        S.n_groups = 1;
-        S.prefix[0] = 0ull;
-        S.clamp_lo = known;        // (field reused: read by rq_finalize_kernel)
+// One wave turns h[0 .. len) (LDS) into its inclusive prefix sums, in place.
+__device__ __forceinline__ void rq_wave_inclusive_scan(unsigned int* h, int len, int lane) {
+    const int per = (len + 63) / 64;
+    const int first = lane * per;
+    unsigned int sum = 0u;
+    for (int i = first; i < first + per && i < len; ++i) sum += h[i];
+    unsigned int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int up = (unsigned int)__shfl_up((int)incl, off, 64);
+        incl += lane >= off ? up : 0u;
     }
-    if (fb) { B.fallback = 1u; S.n_targets = 0; }
-    row_n[row] = fb ? 0u : B.cand_count;
-    row_fallback[row] = fb ? 1u : 0u;
-    if (fb) fb_list[atomicAdd(fb_count, 1u)] = (unsigned int)row;
+    unsigned int run = incl - sum;
+    for (int i = first; i < first + per && i < len; ++i) { run += h[i]; h[i] = run; }
+}
+// first s in [0, len) with x < pre[s] (pre = inclusive prefix sums, x < pre[len - 1])
+__device__ __forceinline__ int rq_upper_bound(const unsigned int* pre, int len, unsigned long long x) {
+    int lo = 0, hi = len - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (x < (unsigned long long)pre[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
 }
 
-// Interpolate the rows that were decided on their candidates (the fallback rows are written by the radix passes).
-__global__ void rq_finalize_kernel(const RqRow* st, const RqBracket* br, const unsigned int* row_fallback, int n_q, int n_rows,
-                                   double* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * n_q) return;
-    const int row = i / n_q, t = i % n_q;
-    if (row_fallback[row]) return;
-    const RqRow& S = st[row];
-    double r;
-    if (S.n_valid == 0) {
-        r = __longlong_as_double(0x7ff8000000000000LL);
-    } else {
-        double a = S.value[2 * t], b = S.value[2 * t + 1];
-        const double g = S.gamma[t];
-        if ((S.clamp_lo >> t) & 1u) a = b = value_of(br[row].lo[br[row].interval_of_q[t]]);   // one-key interval
-        const double diff = b - a;                       // _lerp
-        r = a + diff * g;
-        if (g >= 0.5) r = b - diff * (1.0 - g);
+// (3) Fine brackets.  Per row: the counts of the sample pass say where the sample's order statistics 5 sigma either
+// side of every quantile lie — in which sub-bin of which coarse interval; the edges of those sub-bins are key bounds
+// that contain the wanted order statistics of the WHOLE row with overwhelming probability (and exactness is checked
+// against the slab's own counts afterwards).  A row whose window leaves its coarse interval takes the radix route.
+__global__ __launch_bounds__(256) void rq_refine_kernel(int64_t m, const RqArgs args, const RqBracket* br1, const unsigned int* hist1,
+                                                       RqBracket* br2, unsigned int* hist2, int sub_bits2, unsigned int* gfill) {
+    extern __shared__ __align__(16) unsigned int pre[];   // [n_intervals][1024]: inclusive prefix sums of the sub-histograms
+    __shared__ unsigned long long below[kRqMaxQ], upto[kRqMaxQ], qlo[kRqMaxQ], qhi[kRqMaxQ];
+    __shared__ unsigned int miss;
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const RqBracket& B1 = br1[row];
+    RqBracket& B2 = br2[row];
+    unsigned int* h2 = hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins;
+    for (int k = t; k < kRqMaxQ * kRqMaxSubBins; k += 256) h2[k] = 0u;
+    if (t < kRqMaxT) gfill[(size_t)row * kRqMaxT + t] = 0u;
+    const int nb = B1.n_intervals;
+    constexpr int bins = 1 << kRqCoarseSubBits;
+    if (t == 0) miss = B1.fallback;
+    const unsigned int* h1 = hist1 + (size_t)row * kRqMaxQ * kRqMaxSubBins;
+    for (int k = t; k < nb * bins; k += 256) pre[k] = h1[(k >> kRqCoarseSubBits) * kRqMaxSubBins + (k & (bins - 1))];
+    __syncthreads();
+    for (int b = t >> 6; b < nb; b += 4) rq_wave_inclusive_scan(pre + b * bins, bins, lane);
+    if (t == 0) {
+        unsigned long long run = 0ull;
+        for (int b = 0; b < nb; ++b) {
+            run += B1.pos_count[2 * b]; below[b] = run;
+            run += B1.pos_count[2 * b + 1]; upto[b] = run;
+        }
     }
-    out[(size_t)row * n_q + t] = r;
+    __syncthreads();
+    const unsigned long long mv = (unsigned long long)m - B1.n_nan;   // non-NaN entries of the sample
+    if (t < args.n_q && !miss) {
+        if (mv < 1024ull) {
+            miss = 1u;
+        } else {
+            const double q = args.q[t];
+            const double vi = (double)(mv - 1) * q;
+            const double d = ceil(kRqBracketSigmas * sqrt((double)mv * q * (1.0 - q))) + 2.0;
+            const double rl = floor(vi) - d, rh = floor(vi) + 1.0 + d;
+            const int b = B1.interval_of_q[t];
+            const unsigned long long lo_b = B1.lo[b], hi_b = B1.hi[b];
+            const bool tie = lo_b == hi_b;
+            unsigned long long klo, khi;
+            const bool olo = (B1.open_lo >> t) & 1u, ohi = (B1.open_hi >> t) & 1u;
+            if (rl < 0.0) klo = 0ull;                                        // window open below: whole key range
+            else {
+                const unsigned long long r = (unsigned long long)rl;
+                if (r < below[b] && olo) klo = 0ull;                         // beyond a flagged coarse end: open there too
+                else if (r >= upto[b] && ohi) klo = hi_b;                    // whole window above the flagged top end
+                else if (r < below[b] || r >= upto[b]) { miss = 1u; klo = lo_b; }   // the coarse bracket missed
+                else if (tie) klo = lo_b;
+                else {
+                    const int sb = rq_upper_bound(pre + b * bins, bins, r - below[b]);
+                    if (B1.shift[b] >= 0) klo = lo_b + ((unsigned long long)sb << B1.shift[b]);
+                    else {   // value bins: an edge 1/1000 of a bin on the safe side of the exact one (rounding is far smaller)
+                        klo = B1.inv_w[b] > 0.0 ? key_of(B1.xlo[b] + ((double)sb - 1.0e-3) / B1.inv_w[b]) : lo_b;
+                        if (klo < lo_b) klo = lo_b;
+                    }
+                }
+            }
+            if (rh > (double)(mv - 1)) khi = kRqKeyPosInf;                   // window open above
+            else {
+                const unsigned long long r = (unsigned long long)rh;
+                if (r >= upto[b] && ohi) khi = kRqKeyPosInf;
+                else if (r < below[b] && olo) khi = lo_b;                    // whole window below the flagged bottom end
+                else if (r < below[b] || r >= upto[b]) { miss = 1u; khi = hi_b; }
+                else if (tie) khi = hi_b;
+                else {
+                    const int sb = rq_upper_bound(pre + b * bins, bins, r - below[b]);
+                    if (B1.shift[b] >= 0) {
+                        unsigned long long off = ((unsigned long long)(sb + 1) << B1.shift[b]) - 1ull;
+                        if (off > hi_b - lo_b) off = hi_b - lo_b;           // (also catches the shift wrapping past 2^64)
+                        khi = lo_b + off;
+                    } else {
+                        khi = (B1.inv_w[b] > 0.0 && sb < bins - 1) ? key_of(B1.xlo[b] + ((double)sb + 1.0 + 1.0e-3) / B1.inv_w[b]) : hi_b;
+                        if (khi > hi_b) khi = hi_b;
+                    }
+                }
+            }
+            qlo[t] = klo; qhi[t] = khi;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (miss) { rq_make_intervals(B2, qlo, qhi, 0, sub_bits2); B2.fallback = 1u; }
+        else rq_make_intervals(B2, qlo, qhi, args.n_q, sub_bits2);
+    }
+}
+
+// (5) and (6) Per row, after the slab pass: the true ranks (NumPy `linear`, as rq_scan_kernel computes them) are
+// checked against the counts and located in ONE sub-bin of their interval (a "cell": a few hundred keys, its size
+// known exactly from the sub-histogram).  rq_collect_kernel streams the row's candidates (a few workgroups per row)
+// and appends those of the wanted cells to the row's cell lists; rq_select_kernel then selects each target inside its
+// cell by a per-wave MSD radix select in LDS and interpolates the quantiles.  Both kernels derive the cells with the
+// same deterministic routine.  A row any of whose targets lies outside its interval, whose candidates overflowed,
+// or whose cells do not fit the list is appended to the list of rows for the full radix passes.
+struct RqResolved {   // lives in LDS
+    unsigned long long below[kRqMaxQ], upto[kRqMaxQ], ivlo[kRqMaxQ], ivhi[kRqMaxQ];
+    unsigned long long tgt_res[kRqMaxT], tgt_key[kRqMaxT];
+    unsigned long long m_valid;
+    double gamma_q[kRqMaxQ];
+    double ivxlo[kRqMaxQ], ivinvw[kRqMaxQ];
+    int ivshift[kRqMaxQ];
+    int tgt_cell[kRqMaxT], tgt_b[kRqMaxT], tgt_s[kRqMaxT];
+    int cell_b[kRqMaxT], cell_s[kRqMaxT];
+    unsigned int cell_off[kRqMaxT], cell_size[kRqMaxT];
+    unsigned int fb;
+    int n_cells;
+};
+// All threads of a 1024-thread workgroup.  pre: [kRqMaxQ][bins] u32 (LDS), want: [kRqMaxQ][bins] u8 (LDS) or nullptr.
+__device__ void rq_resolve_row(RqResolved& R, unsigned int* pre, unsigned char* want, int64_t n, const RqArgs& args,
+                               const RqBracket& B, const unsigned int* h2, int sub_bits, unsigned int cand_cap, unsigned int list_cap) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = B.n_intervals;
+    const int bins = 1 << sub_bits;
+    const int nt = 2 * args.n_q;
+    if (t == 0) { R.fb = B.fallback; R.n_cells = 0; R.m_valid = 0ull; }
+    for (int k = t; k < nb * bins; k += 1024) {
+        pre[k] = h2[(k >> sub_bits) * kRqMaxSubBins + (k & (bins - 1))];
+        if (want) want[k] = 255;
+    }
+    __syncthreads();
+    for (int b = wave; b < nb; b += kRqWaves) rq_wave_inclusive_scan(pre + b * bins, bins, lane);
+    if (t == 0 && !R.fb) {
+        unsigned long long run = 0ull, inside = 0ull;
+        for (int b = 0; b < nb; ++b) {
+            run += B.pos_count[2 * b]; R.below[b] = run;
+            run += B.pos_count[2 * b + 1]; R.upto[b] = run;
+            R.ivlo[b] = B.lo[b]; R.ivhi[b] = B.hi[b]; R.ivshift[b] = B.shift[b]; R.ivxlo[b] = B.xlo[b]; R.ivinvw[b] = B.inv_w[b];
+            if (B.lo[b] != B.hi[b]) inside += R.upto[b] - R.below[b];           // one-key intervals stored nothing
+        }
+        R.m_valid = (unsigned long long)n - B.n_nan;
+        if (B.cand_count > cand_cap || inside != (unsigned long long)B.cand_count) R.fb = 1u;
+    }
+    __syncthreads();
+    const unsigned long long m = R.m_valid;
+    if (!R.fb && m > 0 && t < nt) {
+        const int j = t >> 1;
+        const double q = args.q[j];
+        const double vi = (double)(m - 1) * q;                    // _QuantileMethods['linear'].get_virtual_index
+        double prev = floor(vi), next = prev + 1.0;               // _get_indexes
+        if (vi >= (double)(m - 1)) { prev = (double)(m - 1); next = prev; }
+        if (vi < 0.0) { prev = 0.0; next = 0.0; }
+        if ((t & 1) == 0) R.gamma_q[j] = vi - floor(vi);          // _get_gamma (linear: unchanged)
+        const unsigned long long r = (unsigned long long)((t & 1) ? next : prev);
+        const int b = B.interval_of_q[j];
+        R.tgt_b[t] = b; R.tgt_cell[t] = -1; R.tgt_s[t] = 0; R.tgt_res[t] = 0ull; R.tgt_key[t] = 0ull;
+        if (r < R.below[b] || r >= R.upto[b]) R.fb = 1u;          // outside the bracket: not provable here
+        else if (R.ivlo[b] == R.ivhi[b]) R.tgt_key[t] = R.ivlo[b];   // one key: every member IS that value
+        else {
+            const unsigned long long rr = r - R.below[b];
+            if ((unsigned long long)pre[b * bins + bins - 1] != R.upto[b] - R.below[b]) R.fb = 1u;   // (sub-histogram / position counts disagree: never)
+            else {
+                const int s = rq_upper_bound(pre + b * bins, bins, rr);
+                R.tgt_s[t] = s;
+                R.tgt_res[t] = rr - (s ? (unsigned long long)pre[b * bins + s - 1] : 0ull);
+                R.tgt_cell[t] = -2;                               // needs a cell
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0 && !R.fb && m > 0) {   // distinct (interval, sub-bin) cells; sizes are exact
+        unsigned int total = 0u;
+        int nc = 0;
+        for (int a = 0; a < nt; ++a) {
+            if (R.tgt_cell[a] != -2) continue;
+            int c = -1;
+            for (int k = 0; k < nc; ++k)
+                if (R.cell_b[k] == R.tgt_b[a] && R.cell_s[k] == R.tgt_s[a]) { c = k; break; }
+            if (c < 0) {
+                c = nc++;
+                R.cell_b[c] = R.tgt_b[a]; R.cell_s[c] = R.tgt_s[a];
+                const unsigned int* p = pre + R.tgt_b[a] * bins;
+                R.cell_size[c] = p[R.tgt_s[a]] - (R.tgt_s[a] ? p[R.tgt_s[a] - 1] : 0u);
+                R.cell_off[c] = total;
+                total += R.cell_size[c];
+                if (want) want[R.tgt_b[a] * bins + R.tgt_s[a]] = (unsigned char)c;
+            }
+            R.tgt_cell[a] = c;
+        }
+        R.n_cells = nc;
+        if (total > list_cap) R.fb = 1u;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void rq_collect_kernel(int64_t n, const RqArgs args, const RqBracket* br2, const unsigned int* hist2,
+                                                         int sub_bits, const double* __restrict__ cand, unsigned int cand_cap,
+                                                         unsigned int list_cap, unsigned long long* glist, unsigned int* gfill) {
+    extern __shared__ __align__(16) unsigned char dyn[];     // pre u32 [kRqMaxQ][bins] | want u8 [kRqMaxQ][bins]
+    __shared__ RqResolved R;
+    const int row = blockIdx.y, t = threadIdx.x;
+    const RqBracket& B = br2[row];
+    const int bins = 1 << sub_bits;
+    unsigned int* pre = reinterpret_cast<unsigned int*>(dyn);
+    unsigned char* want = dyn + (size_t)kRqMaxQ * bins * sizeof(unsigned int);
+    rq_resolve_row(R, pre, want, n, args, B, hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins, sub_bits, cand_cap, list_cap);
+    if (R.fb || R.m_valid == 0ull || R.n_cells == 0) return;
+    const int nb = B.n_intervals;
+    const double* crow = cand + (size_t)row * cand_cap;        // 16-byte aligned: cand_cap is even
+    unsigned long long* lrow = glist + (size_t)row * list_cap;
+    unsigned int* frow = gfill + (size_t)row * kRqMaxT;
+    const unsigned int cnt = B.cand_count;
+    // the interval ends live in registers (up to 8 intervals: the 7-quantile band set); the search is then pure VALU
+    // and the only LDS traffic per candidate is its interval's (lo, shift) and the `want` byte
+    unsigned long long hi_r[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) hi_r[v] = v < nb ? R.ivhi[v] : ~0ull;
+    const bool small = nb <= 8;
+    auto take = [&](double x, bool ok) {
+        if (!ok) return;
+        const unsigned long long k = key_of(x);
+        int b = 0;
+        if (small) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) b += (k > hi_r[v]) ? 1 : 0;   // intervals are disjoint and ascending: k lies in one
+        } else {
+            for (int v = 0; v < nb; ++v) b += (k > R.ivhi[v]) ? 1 : 0;
+        }
+        const unsigned int c = want[b * bins + rq_sub_bin(k, x, R.ivlo[b], R.ivshift[b], R.ivxlo[b], R.ivinvw[b], bins)];
+        if (c != 255u) {
+            const unsigned int slot = atomicAdd(&frow[c], 1u);
+            if (slot < R.cell_size[c]) lrow[R.cell_off[c] + slot] = k;
+        }
+    };
+    // this workgroup's share of the row's candidates: four 16-byte loads in flight per lane
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t* c2 = reinterpret_cast<const d2_t*>(crow);
+    const unsigned int n_pairs = cnt / 2u;
+    const unsigned int share = (n_pairs + gridDim.x - 1) / gridDim.x;
+    const unsigned int first = blockIdx.x * share;
+    const unsigned int last = first + share < n_pairs ? first + share : n_pairs;
+    constexpr int kUnroll = 4;
+    for (unsigned int base = first; base < last; base += 1024u * kUnroll) {
+        d2_t v[kUnroll];
+        bool ok[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const unsigned int i = base + (unsigned int)u * 1024u + (unsigned int)t;
+            ok[u] = i < last;
+            v[u] = ok[u] ? __builtin_nontemporal_load(&c2[i]) : d2_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) { take(v[u].x, ok[u]); take(v[u].y, ok[u]); }
+    }
+    if ((cnt & 1u) && blockIdx.x == 0 && t == 0) take(crow[cnt - 1u], true);
+}
+
+__global__ __launch_bounds__(1024) void rq_select_kernel(int64_t n, const RqArgs args, RqBracket* br2, const unsigned int* hist2,
+                                                        int sub_bits, unsigned int cand_cap, unsigned int list_cap,
+                                                        const unsigned long long* glist, const unsigned int* gfill, double* out,
+                                                        unsigned long long* counts, unsigned int* row_fallback, unsigned int* fb_list,
+                                                        unsigned int* fb_count) {
+    extern __shared__ __align__(16) unsigned char dyn[];     // pre u32 [kRqMaxQ][bins] | list u64 [list_cap]
+    __shared__ RqResolved R;
+    __shared__ unsigned int whist[kRqWaves * 256];
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    RqBracket& B = br2[row];
+    const int bins = 1 << sub_bits;
+    unsigned int* pre = reinterpret_cast<unsigned int*>(dyn);
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(dyn + (size_t)kRqMaxQ * bins * sizeof(unsigned int));
+    rq_resolve_row(R, pre, nullptr, n, args, B, hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins, sub_bits, cand_cap, list_cap);
+    const int nt = 2 * args.n_q;
+    const unsigned long long m = R.m_valid;
+    if (!R.fb && m > 0) {   // every cell must have received exactly its keys
+        if (t < R.n_cells && gfill[(size_t)row * kRqMaxT + t] != R.cell_size[t]) R.fb = 1u;
+    }
+    __syncthreads();
+    if (R.fb) {
+        if (t == 0) { B.fallback = 1u; row_fallback[row] = 1u; fb_list[atomicAdd(fb_count, 1u)] = (unsigned int)row; }
+        return;
+    }
+    if (t == 0) { row_fallback[row] = 0u; if (counts) counts[row] = m; }
+    if (m == 0) {   // all-NaN row -> NaN (pandas na_value)
+        if (t < args.n_q) out[(size_t)row * args.n_q + t] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    {
+        unsigned int total = 0u;
+        if (R.n_cells > 0) total = R.cell_off[R.n_cells - 1] + R.cell_size[R.n_cells - 1];
+        const unsigned long long* lrow = glist + (size_t)row * list_cap;
+        for (unsigned int i = t; i < total; i += 1024u) list[i] = lrow[i];
+    }
+    __syncthreads();
+    // one wave per target: MSD radix select (8-bit digits) of rank tgt_res inside its cell, starting at the first
+    // digit in which the cell's bounds differ
+    for (int tg = wave; tg < nt; tg += kRqWaves) {
+        const int c = R.tgt_cell[tg];
+        if (c < 0) continue;
+        // key bins: the cell's bounds share their leading digits; value bins: start from the top digit
+        const int csh = R.ivshift[R.cell_b[c]];
+        const unsigned long long clo = csh >= 0 ? R.ivlo[R.cell_b[c]] + ((unsigned long long)R.cell_s[c] << csh) : 0ull;
+        const unsigned long long chi = csh >= 0 ? clo + ((1ull << csh) - 1ull) : ~0ull;
+        const unsigned long long diff = clo ^ chi;
+        int pass = diff ? (__clzll((long long)diff) >> 3) : 8;
+        unsigned long long prefix = pass ? (clo >> (64 - 8 * pass)) : 0ull;
+        unsigned long long rank = R.tgt_res[tg];
+        const unsigned long long* L = list + R.cell_off[c];
+        const unsigned int len = R.cell_size[c];
+        unsigned int* h = whist + wave * 256;
+        for (; pass < 8; ++pass) {
+            const int shift_digit = 56 - 8 * pass;
+            h[lane] = 0u; h[lane + 64] = 0u; h[lane + 128] = 0u; h[lane + 192] = 0u;
+            for (unsigned int i = lane; i < len; i += 64u) {
+                const unsigned long long k = L[i];
+                if (pass == 0 || (k >> (shift_digit + 8)) == prefix) atomicAdd(&h[(unsigned int)(k >> shift_digit) & 0xFFu], 1u);
+            }
+            const unsigned long long c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+            unsigned long long incl = c0 + c1 + c2 + c3;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
+                incl += lane >= off ? up : 0ull;
+            }
+            const unsigned long long excl = incl - (c0 + c1 + c2 + c3);
+            const unsigned long long hit = __ballot(rank >= excl && rank < incl);   // exactly one lane (rank < cell size)
+            const int Lh = hit ? __ffsll((long long)hit) - 1 : 63;
+            int d = 4 * lane;
+            unsigned long long cum = excl;
+            if (rank >= cum + c0) { cum += c0; ++d; if (rank >= cum + c1) { cum += c1; ++d; if (rank >= cum + c2) { cum += c2; ++d; } } }
+            d = __shfl(d, Lh, 64);
+            cum = (unsigned long long)__shfl((long long)cum, Lh, 64);
+            rank -= cum;
+            prefix = (prefix << 8) | (unsigned long long)d;
+        }
+        if (lane == 0) R.tgt_key[tg] = prefix;
+    }
+    __syncthreads();
+    if (t < args.n_q) {
+        const double a = value_of(R.tgt_key[2 * t]), b = value_of(R.tgt_key[2 * t + 1]), g = R.gamma_q[t];
+        const double diff = b - a;                       // _lerp
+        double r = a + diff * g;
+        if (g >= 0.5) r = b - diff * (1.0 - g);
+        out[(size_t)row * args.n_q + t] = r;
+    }
 }
 
 // ---- K2: successful-cohort min/max and equal-width histogram ------------------------------------
@@ -826,9 +1212,13 @@ struct RqLayout {
     unsigned int* aux;
     unsigned long long* cand;
     size_t reduce_offset, reduce_words;
-    // bracketed single pass (mcr_row_quantiles only)
-    RqBracket* br;
-    unsigned int* row_n;
+    // bracketed single pass (mcr_row_quantiles only): coarse / fine brackets and their sub-histograms
+    RqBracket* br1;
+    RqBracket* br2;
+    unsigned int* hist1;        // [n_rows][kRqMaxQ][kRqMaxSubBins]
+    unsigned int* hist2;
+    unsigned long long* glist;  // [n_rows][kRqListCap]: keys of the wanted cells
+    unsigned int* gfill;        // [n_rows][kRqMaxT]: keys appended per cell
     unsigned int* row_fallback;
     unsigned int* fb_list;      // rows that take the full radix passes, and how many
     unsigned int* fb_count;
@@ -845,19 +1235,27 @@ static RqLayout rq_layout(void* scratch, int32_t n_rows, int64_t n = 0) {
     const size_t off_aux = L.reduce_offset + (size_t)n_rows * kRqMaxT * 256 * sizeof(unsigned int);
     const size_t off_cand = L.reduce_offset + ((L.reduce_words + 1) & ~(size_t)1) * sizeof(unsigned int);  // 8-byte aligned
     const size_t off_br = rq_align16(off_cand + (size_t)n_rows * (size_t)rq_cand_cap(n) * sizeof(unsigned long long));
-    const size_t off_rn = rq_align16(off_br + (size_t)n_rows * sizeof(RqBracket));
-    const size_t off_bc = rq_align16(off_rn + ((size_t)n_rows * 3 + 1) * sizeof(unsigned int));
+    const size_t off_rn = rq_align16(off_br + (size_t)n_rows * 2 * sizeof(RqBracket));
+    const size_t off_h = rq_align16(off_rn + ((size_t)n_rows * 2 + 1) * sizeof(unsigned int));
+    const size_t hist_bytes = (size_t)n_rows * kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int);
+    const size_t off_gl = rq_align16(off_h + 2 * hist_bytes);
+    const size_t off_gf = rq_align16(off_gl + (size_t)n_rows * kRqListCap * sizeof(unsigned long long));
+    const size_t off_bc = rq_align16(off_gf + (size_t)n_rows * kRqMaxT * sizeof(unsigned int));
     L.total_bytes = off_bc + (size_t)n_rows * (size_t)rq_bracket_cand_cap(n) * sizeof(double);
     char* base = (char*)scratch;
     L.st = (RqRow*)base;
     L.hist = (unsigned int*)(base + L.reduce_offset);
     L.aux = (unsigned int*)(base + off_aux);
     L.cand = (unsigned long long*)(base + off_cand);
-    L.br = (RqBracket*)(base + off_br);
-    L.row_n = (unsigned int*)(base + off_rn);
-    L.row_fallback = L.row_n + n_rows;
+    L.br1 = (RqBracket*)(base + off_br);
+    L.br2 = L.br1 + n_rows;
+    L.row_fallback = (unsigned int*)(base + off_rn);
     L.fb_list = L.row_fallback + n_rows;
     L.fb_count = L.fb_list + n_rows;
+    L.hist1 = (unsigned int*)(base + off_h);
+    L.hist2 = (unsigned int*)(base + off_h + hist_bytes);
+    L.glist = (unsigned long long*)(base + off_gl);
+    L.gfill = (unsigned int*)(base + off_gf);
     L.bcand = (double*)(base + off_bc);
     return L;
 }
@@ -898,8 +1296,7 @@ int mcr_row_quantiles_begin(void* scratch, int32_t n_rows, int device, void* hip
 
 static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
                         int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax,
-                        const unsigned int* row_n = nullptr, const unsigned int* row_list = nullptr, int n_list = 0,
-                        int slow_cap = 512);
+                        const unsigned int* row_list = nullptr, int n_list = 0);
 
 int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
                            int32_t pass, void* scratch, int device, void* hip_stream) {
@@ -909,7 +1306,7 @@ int mcr_row_quantiles_hist(const double* rows, int64_t row_stride, int32_t n_row
 
 static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int32_t n_q,
                         int32_t pass, void* scratch, int device, void* hip_stream, int track_minmax,
-                        const unsigned int* row_n, const unsigned int* row_list, int n_list, int slow_cap) {
+                        const unsigned int* row_list, int n_list) {
     MCR_ENTER_DEVICE(device);
     int rc = MCR_OK;
     rc = rq_check(scratch, n_rows, n_local, n_q);
@@ -927,18 +1324,18 @@ static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, 
         const dim3 grid(bx, gy), block(kRqBlock);
         // rows whose candidates overflowed (big ties) re-stream alone; the workgroups of all other rows exit at
         // once, and since that is the common case the grid stays modest (idle workgroups cost ~10 ns each)
-        const dim3 grid_slow(grid_for(n, kRqBlock * 16, slow_cap), gy);
+        const dim3 grid_slow(grid_for(n, kRqBlock * 16, 512), gy);
         const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);  // <= 2 targets per quantile
         const size_t lds_first = 256 * sizeof(unsigned int);
         if (pass == 0) {
-            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, track_minmax, row_n, row_list);
+            hipLaunchKernelGGL((rq_hist_kernel<true, false>), grid, block, lds_first, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, track_minmax, row_list);
         } else if (pass < 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0, row_n, row_list);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0, row_list);
         } else if (pass == 3) {
-            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0, row_n, row_list);
+            hipLaunchKernelGGL((rq_hist_kernel<false, true>), grid, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 0, 0, row_list);
         } else {
             hipLaunchKernelGGL(rq_cand_hist_kernel, dim3(16, gy), block, lds_groups, s, pass, L.st, L.hist, L.aux, L.cand, cap, row_list);
-            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1, 0, row_n, row_list);
+            hipLaunchKernelGGL((rq_hist_kernel<false, false>), grid_slow, block, lds_groups, s, rows, row_stride, n, pass, L.st, L.hist, L.aux, L.cand, cap, 1, 0, row_list);
         }
     }
     if (pass == 3) hipLaunchKernelGGL(rq_flag_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, L.st, L.aux, n_rows, cap);
@@ -948,7 +1345,7 @@ static int rq_hist_step(const double* rows, int64_t row_stride, int32_t n_rows, 
 }
 
 static int rq_scan_step(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
-                        uint64_t* counts, void* scratch, int device, void* hip_stream, int mode,
+                        uint64_t* counts, void* scratch, int device, void* hip_stream,
                         const unsigned int* row_list, int n_list) {
     MCR_ENTER_DEVICE(device);
     int rc = MCR_OK;
@@ -964,7 +1361,7 @@ static int rq_scan_step(int32_t n_rows, int64_t n_total, const double* q, int32_
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
     const size_t lds_groups = (size_t)(2 * n_q) * 256 * sizeof(unsigned int);
     hipLaunchKernelGGL(rq_scan_kernel, dim3(row_list ? n_list : n_rows), dim3(kRqScanBlock), lds_groups, (hipStream_t)hip_stream, n_total, pass,
-                       L.st, L.hist, a, out, (unsigned long long*)counts, L.aux, mode, row_list);
+                       L.st, L.hist, a, out, (unsigned long long*)counts, L.aux, row_list);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rq_scan_kernel");
     return MCR_OK;
@@ -972,19 +1369,17 @@ static int rq_scan_step(int32_t n_rows, int64_t n_total, const double* q, int32_
 
 int mcr_row_quantiles_scan(int32_t n_rows, int64_t n_total, const double* q, int32_t n_q, int32_t pass, double* out,
                            uint64_t* counts, void* scratch, int device, void* hip_stream) {
-    return rq_scan_step(n_rows, n_total, q, n_q, pass, out, counts, scratch, device, hip_stream, kRqQuantiles, nullptr, 0);
+    return rq_scan_step(n_rows, n_total, q, n_q, pass, out, counts, scratch, device, hip_stream, nullptr, 0);
 }
 
 // The full radix select (8 digit passes) over rows of length n: all rows, or the n_list rows listed in row_list.
 static int rq_radix_select(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n, const double* q, int32_t n_q,
-                           double* out, uint64_t* counts, void* scratch, int device, void* hip_stream, int mode,
-                           const unsigned int* row_n, const unsigned int* row_list, int n_list) {
+                           double* out, uint64_t* counts, void* scratch, int device, void* hip_stream,
+                           const unsigned int* row_list, int n_list) {
     int rc = MCR_OK;
     for (int pass = 0; pass < 8 && rc == MCR_OK; ++pass) {
-        rc = rq_hist_step(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream,
-                          /*track_minmax=*/mode == kRqQuantiles ? 1 : 0, row_n, row_list, n_list,
-                          /*slow_cap=*/mode == kRqQuantiles ? 512 : 32);   // the sample / candidate selects are short rows
-        if (rc == MCR_OK) rc = rq_scan_step(n_rows, n, q, n_q, pass, out, counts, scratch, device, hip_stream, mode, row_list, n_list);
+        rc = rq_hist_step(rows, row_stride, n_rows, n, n_q, pass, scratch, device, hip_stream, /*track_minmax=*/1, row_list, n_list);
+        if (rc == MCR_OK) rc = rq_scan_step(n_rows, n, q, n_q, pass, out, counts, scratch, device, hip_stream, row_list, n_list);
     }
     return rc;
 }
@@ -1004,11 +1399,13 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
                       int32_t n_q, double* out, uint64_t* counts, void* scratch, int device, void* hip_stream) {
     g_last_fallback_rows = -1;
     if (!rows || n <= 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
-    int rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
-    if (rc != MCR_OK) return rc;
-    if (n < rq_bracket_min_n() || n < 4096 || 2 * n_q >= 32)
-        return rq_radix_select(rows, row_stride, n_rows, n, q, n_q, out, counts, scratch, device, hip_stream, kRqQuantiles, nullptr, nullptr, 0);
-
+    MCR_ENTER_DEVICE(device);
+    int rc = MCR_OK;
+    if (n < rq_bracket_min_n() || n < kRqTiny || 2 * n_q >= 32) {
+        rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+        if (rc != MCR_OK) return rc;
+        return rq_radix_select(rows, row_stride, n_rows, n, q, n_q, out, counts, scratch, device, hip_stream, nullptr, 0);
+    }
     rc = rq_check(scratch, n_rows, n, n_q);
     if (rc != MCR_OK) return rc;
     if (!q || !out || row_stride < n) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
@@ -1020,37 +1417,60 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     std::memset(&a, 0, sizeof(a));
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
-    // (1) brackets from a sample: the first n/32 entries of every row (paths are exchangeable; an unlucky or
-    //     adversarial prefix only costs the affected rows the fallback below)
+    {   // kernels whose dynamic LDS request can exceed the 64 KB default
+        static thread_local int lds_opt_in_device = -1;
+        if (lds_opt_in_device != device) {
+            const int big = 160 * 1024 - 24 * 1024;
+            (void)hipFuncSetAttribute((const void*)rq_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)rq_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)rq_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipGetLastError();
+            lds_opt_in_device = device;
+        }
+    }
+    // (1) coarse brackets from the first kRqTiny entries of every row, sorted in LDS (paths are exchangeable; an
+    //     unlucky or adversarial prefix only costs the affected rows the fallback below)
+    hipLaunchKernelGGL(rq_tiny_kernel, dim3(n_rows), dim3(1024), 0, s, rows, row_stride, a, L.br1, L.hist1, L.fb_count);
+    // (2) the counting pass over a sample (the first n/32 entries), (3) fine brackets from its counts
     int64_t m = n / 32;
     if (m < 65536) m = 65536;
     if (m > n) m = n;
     m &= ~(int64_t)1;
-    rc = rq_radix_select(rows, row_stride, n_rows, m, q, n_q, out, nullptr, scratch, device, hip_stream, kRqSample, nullptr, nullptr, 0);
-    if (rc != MCR_OK) return rc;
-    hipLaunchKernelGGL(rq_bracket_prep_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, L.st, L.br, (int)n_q, (int)n_rows, L.fb_count);
-    // (2) the one pass over the slab
+    const int sub_bits2 = n <= ((int64_t)1 << 24) ? 8 : 10;   // cells of a few hundred keys either way
+    const bool small_p = 2 * n_q < 16;                        // bound table: the next power of two above 2 * (intervals <= quantiles)
     const unsigned int bcap = rq_bracket_cand_cap(n);
-    {
-        const int bx = grid_for(n, kRqBlock * 16, 4096 / n_rows > 0 ? 4096 / n_rows : 1);
+    auto count_pass = [&](int64_t len, RqBracket* br, unsigned int* hist, int sub_bits, bool compact) {
+        // slab pass: ~4096 workgroups in flight; sample pass: few per row — every workgroup flushes its sub-histograms
+        // (up to 1024 bins per interval) with global atomics, and the sample is only 1/32 of the slab
+        const int per_row = compact ? (4096 / n_rows > 0 ? 4096 / n_rows : 1) : (1024 / n_rows > 1 ? 1024 / n_rows : 2);
+        const int bx = grid_for(len, kRqBlock * 16, per_row);
         const dim3 grid(bx, n_rows), block(kRqBlock);
-#define MCR_BRACKET(P) hipLaunchKernelGGL((rq_bracket_kernel<P>), grid, block, 0, s, rows, row_stride, n, L.br, L.bcand, bcap)
-        if (2 * n_q < 16) MCR_BRACKET(16);        // bound table: the next power of two above 2 * (intervals <= quantiles)
-        else MCR_BRACKET(32);
-#undef MCR_BRACKET
+        const size_t lds = (size_t)(small_p ? 8 : 16) * ((size_t)1 << sub_bits) * sizeof(unsigned int);
+#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, L.bcand, bcap)
+        if (small_p) { if (compact) MCR_COUNT(16, true); else MCR_COUNT(16, false); }
+        else { if (compact) MCR_COUNT(32, true); else MCR_COUNT(32, false); }
+#undef MCR_COUNT
+    };
+    count_pass(m, L.br1, L.hist1, kRqCoarseSubBits, false);
+    hipLaunchKernelGGL(rq_refine_kernel, dim3(n_rows), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), s, m, a, L.br1,
+                       L.hist1, L.br2, L.hist2, sub_bits2, L.gfill);
+    // (4) the one pass over the slab
+    count_pass(n, L.br2, L.hist2, sub_bits2, true);
+    // (5) ranks -> cells; the candidates of the wanted cells; (6) selection in LDS -> interpolation
+    {
+        const size_t bins = (size_t)1 << sub_bits2;
+        const unsigned int list_cap = sub_bits2 == 8 ? kRqListCap : kRqListCap / 2;
+        const int per_row = n >= ((int64_t)1 << 23) ? 8 : (n >= ((int64_t)1 << 21) ? 4 : 2);   // a few MB of candidates per row
+        hipLaunchKernelGGL(rq_collect_kernel, dim3(per_row, n_rows), dim3(1024), (size_t)kRqMaxQ * bins * 5, s, n, a, L.br2, L.hist2, sub_bits2,
+                           L.bcand, bcap, list_cap, L.glist, L.gfill);
+        const size_t lds = (size_t)kRqMaxQ * bins * sizeof(unsigned int) + (size_t)list_cap * sizeof(unsigned long long);
+        hipLaunchKernelGGL(rq_select_kernel, dim3(n_rows), dim3(1024), lds, s, n, a, L.br2, L.hist2, sub_bits2, bcap, list_cap, L.glist, L.gfill,
+                           out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count);
     }
-    // (3) ranks among the candidates, then the select on the candidate buffers (ragged rows)
-    rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
-    if (rc != MCR_OK) return rc;
-    hipLaunchKernelGGL(rq_resolve_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, n, a, L.br, L.st, L.row_n, L.row_fallback,
-                       L.fb_list, L.fb_count, (unsigned long long*)counts, bcap, (int)n_rows);
-    rc = rq_radix_select(L.bcand, (int64_t)bcap, n_rows, (int64_t)bcap, q, n_q, out, nullptr, scratch, device, hip_stream,
-                         kRqExplicit, L.row_n, nullptr, 0);
-    if (rc != MCR_OK) return rc;
-    hipLaunchKernelGGL(rq_finalize_kernel, dim3((n_rows * n_q + 255) / 256), dim3(256), 0, s, L.st, L.br, L.row_fallback, (int)n_q,
-                       (int)n_rows, out);
-    // (4) rows the brackets could not decide (a target outside its bracket, candidates overflowing on a wide tie
-    //     that straddles a bracket end, an all-NaN sample) take the full passes.  How many is only known on the
+    // (6) rows the brackets could not decide (a target outside its bracket, candidates overflowing on a wide tie
+    //     that straddles a bracket end, a sample without data) take the full passes.  How many is only known on the
     //     device: this route reads one word back (ONE stream synchronisation per call) rather than launch eight
     //     passes of idle workgroups.
     unsigned int n_fb = 0;
@@ -1061,8 +1481,7 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     if (n_fb > 0) {
         rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
         if (rc != MCR_OK) return rc;
-        rc = rq_radix_select(rows, row_stride, n_rows, n, q, n_q, out, counts, scratch, device, hip_stream, kRqQuantiles, nullptr,
-                             L.fb_list, (int)n_fb);
+        rc = rq_radix_select(rows, row_stride, n_rows, n, q, n_q, out, counts, scratch, device, hip_stream, L.fb_list, (int)n_fb);
         if (rc != MCR_OK) return rc;
     }
     e = hipGetLastError();

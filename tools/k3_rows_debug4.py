@@ -1,0 +1,17 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from monte_carlo_retirement_amd import aggregation as A
+n = 1 << 22
+rng = np.random.default_rng(3)
+rows = np.empty((3, n))
+rows[0] = rng.lognormal(14, 1.2, n)
+rows[1] = np.where(rng.random(n) < 0.2, np.nan, rng.normal(4.0, 1.5, n))
+rows[2] = 1.0e6
+nine = (0.01, 0.05, 0.10, 0.25, 0.50, 0.75, 0.90, 0.95, 0.99)
+for qs in (nine, nine[:8], nine[1:], (0.01, 0.5, 0.99, 0.3, 0.4, 0.6, 0.7, 0.8), tuple(np.linspace(0.1, 0.9, 9)), tuple(np.linspace(0.1, 0.9, 12))):
+    fb = []
+    for r in range(3):
+        A.row_quantiles(torch.as_tensor(rows[r:r + 1], device="cuda"), n, qs)
+        fb.append(A.last_fallback_rows())
+    print(len(qs), qs[:3], fb)
