@@ -91,16 +91,20 @@ def aux_hbm_kernels(torch, n):
     bytes_k3 = 8 * n * (2 * T + ry)      # algorithmic: every entry of the slab has to be read once
     ms_k2 = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 100))
     bytes_k2 = 2 * 9 * n                 # min/max pass + bin pass, 8 B value + 1 B flag each
-    profiled = None   # the slab pass alone, from the committed rocprofv3 summary of this same command
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_final", "pmc_summary.json")) as fh:
-            dv = json.load(fh)["derived"]
-        profiled = {"kernel": "mcr::rq_bracket_kernel", "ms": dv["K3_bracket_avg_ms_from_kernel_stats"],
-                    "achieved_TBps": dv["K3_bracket_achieved_TBps"], "frac_of_hbm_peak": dv["K3_bracket_achieved_TBps"] * 1e3 / HBM_PEAK_GBS,
-                    "traffic_over_algorithmic": dv["K3_bracket_traffic_over_algorithmic"],
-                    "source": "profiles/r01_final/pmc_summary.json (rocprofv3 --kernel-trace --stats + FETCH_SIZE/WRITE_SIZE passes)"}
-    except (OSError, KeyError, ValueError):
-        pass
+    profiled = None   # the slab pass alone, from the committed rocprofv3 summary of this same command (latest round)
+    for rnd in ("r02", "r01_final"):
+        try:
+            with open(os.path.join(REPO, "profiles", rnd, "pmc_summary.json")) as fh:
+                dv = json.load(fh)["derived"]
+            profiled = {"kernel": "mcr::rq_count_kernel<16, true>" if rnd != "r01_final" else "mcr::rq_bracket_kernel",
+                        "ms": dv["K3_bracket_avg_ms_from_kernel_stats"], "achieved_TBps": dv["K3_bracket_achieved_TBps"],
+                        "frac_of_hbm_peak": dv["K3_bracket_achieved_TBps"] * 1e3 / HBM_PEAK_GBS,
+                        "traffic_over_algorithmic": dv["K3_bracket_traffic_over_algorithmic"],
+                        "paths": 10_000_000 if rnd != "r01_final" else 4_000_000,
+                        "source": f"profiles/{rnd}/pmc_summary.json (rocprofv3 --kernel-trace --stats + FETCH_SIZE/WRITE_SIZE passes)"}
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     return {
         "workload": f"BASELINE configs[2] shape: jorge.json rho=0.3, wm=75 (555 months), {n} paths, T={T}, ry={ry}",
         "K1_full_output": {"ms": ms_k1, "paths_per_s": n / ms_k1 * 1e3, "algorithmic_write_bytes": bytes_k1,
@@ -109,9 +113,9 @@ def aux_hbm_kernels(torch, n):
         "K3_row_quantiles": {"ms": ms_k3, "rows": 2 * T + ry, "algorithmic_read_bytes": bytes_k3,
                              "GBps": bytes_k3 / ms_k3 / 1e6, "frac_of_hbm_peak": bytes_k3 / ms_k3 / 1e6 / HBM_PEAK_GBS,
                              "fallback_rows": fallback_rows, "slab_pass_profiled": profiled,
-                             "note": "one call over the [2T+ry] slab (bands of all rows), incl. scratch allocation and result download. "
-                                     "Algorithmic bytes = ONE read of the slab; the bracket pass that does it runs at ~5 TB/s, the rest of "
-                                     "the time is the sample select before it and the candidate select after it (profiles/). "
+                             "note": "one call over the [2T+ry] slab (bands of all rows): six launches + one word read back, incl. the result "
+                                     "download. Algorithmic bytes = ONE read of the slab; the counting pass that does it runs at ~5 TB/s, the "
+                                     "rest is the two sampling steps before it and the per-row cell selection after it (profiles/). "
                                      "fallback_rows = rows that needed the 4-pass radix select (-1: rows too short for the bracketed route)"},
         "K2_histogram": {"ms": ms_k2, "algorithmic_bytes": bytes_k2, "GBps": bytes_k2 / ms_k2 / 1e6},
     }

@@ -29,7 +29,7 @@ def band_quantiles(batch, n: int, reduce_counts=None, n_total: Optional[int] = N
     [2T+ry, stride] slab: ``(trajectory_q[T,7], real_trajectory_q[T,7], wr_q[ry,5], wr_counts[ry])``.
     The WR percentile set is a subset of the trajectory set, so the WR rows simply keep 5 of the 7 columns."""
     T = batch.sizes.trajectory_len
-    q, counts = row_quantiles(batch.slab, n, TRAJECTORY_QUANTILES, reduce_counts=reduce_counts, n_total=n_total)
+    q, counts = row_quantiles(batch.slab, n, TRAJECTORY_QUANTILES, reduce_counts=reduce_counts, n_total=n_total, scratch_owner=batch)
     return q[:T], q[T:2 * T], np.ascontiguousarray(q[2 * T:][:, _WR_COLS]), counts[2 * T:]
 
 
@@ -40,7 +40,7 @@ def _pandas_q(qs: Sequence[float]) -> np.ndarray:
 
 
 def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0, reduce_counts=None,
-                  n_total: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+                  n_total: Optional[int] = None, scratch_owner=None) -> Tuple[np.ndarray, np.ndarray]:
     """Quantiles of each row of a device tensor ``rows[n_rows, stride]`` over its first ``n``
     entries, NaNs skipped — ``DataFrame(rows.T).quantile(qs, axis=0)`` semantics.
 
@@ -61,19 +61,36 @@ def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0, reduce_cou
     n_rows = int(rows.shape[0])
     q = _pandas_q(qs)
     dev = rows.device
-    out = torch.empty((n_rows, len(q)), dtype=torch.float64, device=dev)
-    counts = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+    # quantiles [n_rows, n_q] (float64) and counts [n_rows] (uint64) share ONE device buffer: one download, one sync
+    res = torch.empty(n_rows * (len(q) + 1), dtype=torch.float64, device=dev)
+    out, counts = res[:n_rows * len(q)], res[n_rows * len(q):]
     nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q), int(n)))
     if nbytes <= 0:
         raise ValueError("unsupported number of rows / quantiles")
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    scratch = _scratch(scratch_owner, nbytes, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc = lib.mcr_row_quantiles(
         rows.data_ptr(), int(rows.stride(0)), n_rows, int(n), q.ctypes.data, len(q),
         out.data_ptr(), counts.data_ptr(), scratch.data_ptr(), dev.index or 0, C.c_void_p(stream),
     )
     N.check(rc, "mcr_row_quantiles")
-    return out.cpu().numpy(), counts.cpu().numpy()
+    host = res.cpu().numpy()
+    return host[:n_rows * len(q)].reshape(n_rows, len(q)), host[n_rows * len(q):].view(np.uint64).astype(np.int64)
+
+
+def _scratch(owner, nbytes: int, dev):
+    """Scratch buffer of a selection call.  A caller that selects repeatedly over the same batch (the bands of a
+    DeviceBatch, then the summary statistics) passes the batch as `owner`: the buffer then lives and dies with it."""
+    import torch
+
+    if owner is not None:
+        buf = getattr(owner, "_rq_scratch", None)
+        if buf is not None and buf.numel() >= nbytes and buf.device == dev:
+            return buf
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if owner is not None:
+        owner._rq_scratch = buf
+    return buf
 
 
 def last_fallback_rows() -> int:

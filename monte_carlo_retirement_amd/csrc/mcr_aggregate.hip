@@ -1127,13 +1127,46 @@ __global__ __launch_bounds__(256) void minmax_init_kernel(double* minmax) {
     }
 }
 
+// Streaming helper of the two K2 passes: every lane takes PAIRS of paths — one 16-byte value load and one 2-byte flag
+// load per pair, four pairs in flight — and hands each successful value to `f`.  (values 16-byte, flags 2-byte aligned:
+// the caller checks; a stray last element is taken by one lane.)
+template <typename F>
+__device__ __forceinline__ void k2_stream(const double* __restrict__ v, const uint8_t* __restrict__ ok, int64_t n, bool vec2, F&& f) {
+    const int64_t step = (int64_t)gridDim.x * 256;
+    if (vec2) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t* v2 = reinterpret_cast<const d2_t*>(v);
+        const unsigned short* ok2 = reinterpret_cast<const unsigned short*>(ok);
+        const int64_t n_pairs = n / 2;
+        constexpr int kUnroll = 4;
+        for (int64_t base = (int64_t)blockIdx.x * 256 + threadIdx.x; base < n_pairs; base += step * kUnroll) {
+            d2_t x[kUnroll];
+            unsigned int fl[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t i = base + u * step;
+                const bool in = i < n_pairs;
+                x[u] = in ? __builtin_nontemporal_load(&v2[i]) : d2_t{0.0, 0.0};
+                fl[u] = in ? (unsigned int)ok2[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (fl[u] & 0xFFu) f(x[u].x);
+                if (fl[u] >> 8) f(x[u].y);
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0 && ok[n - 1]) f(v[n - 1]);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step)
+            if (ok[i]) f(v[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ v, const uint8_t* __restrict__ ok,
-                                                    int64_t n, double* minmax) {
+                                                    int64_t n, double* minmax, int vec2) {
     __shared__ double smin[4], smax[4];
     double lo = __longlong_as_double(0x7ff0000000000000LL), hi = -lo;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (ok[i]) { const double x = v[i]; lo = fmin(lo, x); hi = fmax(hi, x); }
-    }
+    k2_stream(v, ok, n, vec2 != 0, [&](double x) { lo = fmin(lo, x); hi = fmax(hi, x); });
     for (int off = 32; off > 0; off >>= 1) {
         lo = fmin(lo, __shfl_down(lo, off, 64));
         hi = fmax(hi, __shfl_down(hi, off, 64));
@@ -1168,7 +1201,7 @@ __global__ __launch_bounds__(256) void stat_rows_kernel(const double* __restrict
 // +-1 correction against the linspace edges.
 __global__ __launch_bounds__(256) void hist_kernel(const double* __restrict__ v, const uint8_t* __restrict__ ok,
                                                   int64_t n, const double* __restrict__ minmax, int n_bins,
-                                                  unsigned long long* bins) {
+                                                  unsigned long long* bins, int vec2) {
     extern __shared__ unsigned int lbins[];
     for (int k = threadIdx.x; k < n_bins; k += 256) lbins[k] = 0u;
     __syncthreads();
@@ -1176,10 +1209,8 @@ __global__ __launch_bounds__(256) void hist_kernel(const double* __restrict__ v,
     if (lo == hi) { lo = lo - 0.5; hi = hi + 0.5; }  // _get_outer_edges: degenerate range widened
     const double denom = hi - lo;
     const double step = denom / (double)n_bins;      // np.linspace step
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (!ok[i]) continue;
-        const double x = v[i];
-        if (!(x >= lo && x <= hi)) continue;
+    k2_stream(v, ok, n, vec2 != 0, [&](double x) {
+        if (!(x >= lo && x <= hi)) return;
         int idx = (int)(((x - lo) / denom) * (double)n_bins);
         if (idx == n_bins) idx -= 1;
         const double e_lo = idx == n_bins ? hi : lo + (double)idx * step;
@@ -1189,7 +1220,7 @@ __global__ __launch_bounds__(256) void hist_kernel(const double* __restrict__ v,
             if (x >= e_hi && idx != n_bins - 1) idx += 1;
         }
         atomicAdd(&lbins[idx], 1u);
-    }
+    });
     __syncthreads();
     for (int k = threadIdx.x; k < n_bins; k += 256)
         if (lbins[k]) atomicAdd(&bins[k], (unsigned long long)lbins[k]);
@@ -1494,7 +1525,8 @@ int mcr_minmax_success(const double* values, const uint8_t* success, int64_t n, 
     if (!values || !success || !minmax || n < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, minmax);
-    if (n > 0) hipLaunchKernelGGL(minmax_kernel, dim3(grid_for(n, 256 * 8, 2048)), dim3(256), 0, s, values, success, n, minmax);
+    const int vec2 = ((reinterpret_cast<uintptr_t>(values) & 15) == 0 && (reinterpret_cast<uintptr_t>(success) & 1) == 0) ? 1 : 0;
+    if (n > 0) hipLaunchKernelGGL(minmax_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, s, values, success, n, minmax, vec2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "minmax kernels");
     return MCR_OK;
@@ -1505,8 +1537,9 @@ int mcr_histogram_success(const double* values, const uint8_t* success, int64_t 
     MCR_ENTER_DEVICE(device);
     if (!values || !success || !minmax || !bins || n < 0 || n_bins <= 0 || n_bins > 8192) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
     if (n == 0) return MCR_OK;
-    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n, 256 * 8, 2048)), dim3(256), (size_t)n_bins * sizeof(unsigned int),
-                       (hipStream_t)hip_stream, values, success, n, minmax, (int)n_bins, (unsigned long long*)bins);
+    const int vec2 = ((reinterpret_cast<uintptr_t>(values) & 15) == 0 && (reinterpret_cast<uintptr_t>(success) & 1) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), (size_t)n_bins * sizeof(unsigned int),
+                       (hipStream_t)hip_stream, values, success, n, minmax, (int)n_bins, (unsigned long long*)bins, vec2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hist_kernel");
     return MCR_OK;

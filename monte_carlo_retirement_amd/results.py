@@ -22,7 +22,9 @@ import numpy as np
 import pandas as pd
 
 from . import aggregation as A
+from . import distributed as D
 from . import engine as E
+from ._native import MCR_N_COUNTERS as N_COUNTERS
 from ._logging import logger
 from .config import Config
 from .constants import MONTHS_PER_YEAR, SMALL_EPSILON
@@ -170,35 +172,72 @@ def compact_result(config: Config, simulator: RetirementMonteCarloSimulator, req
     the device — success share from the kernel's counters, medians and final-balance percentiles by the
     radix select over ``mcr_summary_stat_rows`` — and the three per-path lists of ``histogram`` (and the
     per-path ``years_to_ruin`` list) are left empty; ``histogram_binned`` / ``ruin_histogram.bins`` carry
-    the binned equivalents (``np.histogram`` semantics; K1's ruin-year counters).  Single process."""
+    the binned equivalents (``np.histogram`` semantics; K1's ruin-year counters).  Under a process group the
+    path range is sharded over the ranks (below)."""
     wm = int(required_w_months)
     n = int(config.num_simulations_main if num_simulations is None else num_simulations)
     if n <= 0:
         raise ValueError(f"Simulation for '{config.Nickname}' yielded no results.")
     dev = simulator._local_device()
-    batch = E.DeviceBatch(simulator._current_params(), wm, n, want="full", device=dev)
-    batch.launch(simulator._batch_rng(n), simulator._stream_id, 0)
-    ok_count = int(batch.counters[0].item())
+    # One process per GPU (torch.distributed initialised): every rank simulates its shard of the global path range and
+    # keeps it in its own HBM; what crosses ranks is the counter block, the digit histograms of the exact distributed
+    # quantiles, the histogram range / bins and the five sampled columns.  Every rank returns the same document, equal
+    # to the single-GPU one (the Philox counter carries the global path index).
+    sharded = D.is_active()
+    if sharded:
+        import torch.distributed as dist
+
+        begin, count = D.shard_range(n, dist.get_rank(), dist.get_world_size())
+    else:
+        begin, count = 0, n
+    batch = E.DeviceBatch(simulator._current_params(), wm, max(count, 1), want="full", device=dev)
+    if count > 0:
+        batch.launch(simulator._batch_rng(n), simulator._stream_id, begin, count)
+    reduced = batch.reduce_vec.clone()
+    if sharded:
+        if count == 0:
+            reduced.zero_()
+        reduced = reduced.to(D._comm_device())
+        D.all_reduce_sum_(reduced)
+    reduced = reduced.cpu().numpy()
+    ok_count = int(reduced[0])
     # rows: start | final | final of successful paths | first-year real withdrawal rate (%), NaN = not in the cohort
-    stat_rows = A.summary_stat_rows(batch, n)
-    sq, _ = A.row_quantiles(stat_rows, n, FINAL_BALANCE_PERCENTILES)
+    stat_rows = A.summary_stat_rows(batch, count)
+    if sharded:
+        sq, _ = D.sharded_row_quantiles(stat_rows, count, FINAL_BALANCE_PERCENTILES)
+        traj_q, real_q, wr_q, wr_counts = D.sharded_band_quantiles(batch, count)
+    else:
+        sq, _ = A.row_quantiles(stat_rows, n, FINAL_BALANCE_PERCENTILES)
+        traj_q, real_q, wr_q, wr_counts = A.band_quantiles(batch, n)
     median = FINAL_BALANCE_PERCENTILES.index(0.50)
     med_final_ok = float(sq[2, median])
     swr = float(sq[3, median])
-    traj_q, real_q, wr_q, wr_counts = A.band_quantiles(batch, n)
     qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
     samples = real_samples = None
     try:
         picked = np.random.RandomState(simulator.main_seed).choice(n, size=min(n, 5), replace=False)
         from .simulation import _gather_columns
 
-        samples = _gather_columns(batch.trajectory, picked).tolist()
-        real_samples = _gather_columns(batch.real_trajectory, picked).tolist()
+        mine = [(j, int(g) - begin) for j, g in enumerate(picked) if begin <= g < begin + count]
+        both = np.zeros((2, len(picked), batch.sizes.trajectory_len))
+        if mine:
+            cols = [c for _, c in mine]
+            both[0, [j for j, _ in mine]] = _gather_columns(batch.trajectory, cols)
+            both[1, [j for j, _ in mine]] = _gather_columns(batch.real_trajectory, cols)
+        if sharded:   # owner ranks fill their columns, the rest stays 0: a sum is the gather
+            import torch
+
+            buf = torch.as_tensor(both, device=D._comm_device())
+            D.all_reduce_sum_(buf)
+            both = buf.cpu().numpy()
+        samples, real_samples = both[0].tolist(), both[1].tolist()
     except ValueError as ve:
         logger.error(f"Error sampling trajectories: {ve}")
     years = trajectory_time_points(wm, config.retirement_years)
-    bins, edges = A.success_histogram(batch.summary["final_balance"][:n], batch.success[:n], n_bins)
-    ruin_bins = batch.ruin_year_bins.cpu().numpy()
+    bins, edges = A.success_histogram(batch.summary["final_balance"][:count], batch.success[:count], n_bins,
+                                      reduce_range=D.all_reduce_minmax_ if sharded else None,
+                                      reduce_bins=D.all_reduce_sum_ if sharded else None)
+    ruin_bins = reduced[N_COUNTERS + config.retirement_years:]
     doc = {
         "scenario": config.Nickname,
         "summary": _summary_block(

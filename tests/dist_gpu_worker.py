@@ -125,6 +125,13 @@ def main():
     shd = sim2.run_monte_carlo_simulations(wm, 700)
     res["class_replicated_equals_sharded"] = bool(rep[0].equals(shd[0]) and np.array_equal(rep[1].to_numpy(), shd[1].to_numpy(), equal_nan=True)
                                                   and rep[6] == shd[6] and rep[2] == shd[2])
+    # ---- (4) the compact response document of a large batch, from sharded batches: equal to one process's document
+    from monte_carlo_retirement_amd import results as R
+
+    c_sim = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
+    c_sim.use_final_seeds()
+    doc = R.compact_result(cfg, c_sim, wm, num_simulations=n_paths)
+    res["compact_doc"] = doc
     with open(f"{out_path}.{rank}", "w") as fh:
         json.dump(res, fh)
     dist.barrier()

@@ -46,3 +46,15 @@ def test_sharded_quantiles_and_bands_equal_unsharded(tmp_path, world):
         assert r["class_probe_many_by_candidate"] and r["class_probe_many_by_range"] and r["class_speculation_slots"], r
         assert r["class_search_replays_reference"] and r["class_search_batched"], r
         assert r["class_replicated_equals_sharded"], r
+    # the compact document built from sharded batches equals the single-process one (built here, same scenario)
+    from monte_carlo_retirement_amd import Config
+    from monte_carlo_retirement_amd import results as R
+    from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
+
+    with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
+        cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3, initial_balance=20000.0, monthly_contribution=3000.0))
+    sim = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
+    sim.use_final_seeds()
+    whole = json.loads(json.dumps(R.compact_result(cfg, sim, 40, num_simulations=5003)))
+    for r in res:
+        assert r["compact_doc"] == whole, [k for k in whole if r["compact_doc"].get(k) != whole[k]]

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 PATHS_COUNT, MONTHS_COUNT = 1_000_000, 833            # bench.py workload (configs[1])
-PATHS_FULL, T_FULL, RY_FULL = 4_000_000, 48, 40        # bench.py hbm_kernels block (configs[2] shape)
+PATHS_FULL, T_FULL, RY_FULL = 10_000_000, 48, 40       # bench.py hbm_kernels block (configs[2] shape)
 
 
 def label(kernel_name: str):
@@ -23,8 +23,11 @@ def label(kernel_name: str):
     if "path_kernel<0" in k:
         return "K1 path_kernel<0,...> (count-only, 1e6 paths x 833 months)"
     if "path_kernel<2" in k:
-        return "K1 path_kernel<2,...> (full output, 4e6 paths x 555 months)"
-    for tag, name in (("rq_bracket_kernel", "K3 rq_bracket_kernel (the one pass over the slab)"), ("rq_hist", "K3 rq_hist_kernel"),
+        return "K1 path_kernel<2,...> (full output, 1e7 paths x 555 months)"
+    for tag, name in (("rq_count_kernel<16, true>", "K3 rq_count_kernel<16,true> (the one pass over the slab)"),
+                      ("rq_count_kernel<16, false>", "K3 rq_count_kernel<16,false> (sample pass)"),
+                      ("rq_tiny", "K3 rq_tiny_kernel"), ("rq_refine", "K3 rq_refine_kernel"), ("rq_collect", "K3 rq_collect_kernel"),
+                      ("rq_select", "K3 rq_select_kernel"), ("rq_hist", "K3 rq_hist_kernel"),
                       ("rq_cand", "K3 rq_cand_hist_kernel"), ("rq_scan", "K3 rq_scan_kernel")):
         if tag in k:
             return name
@@ -49,8 +52,7 @@ def main(src: str, dst: str) -> None:
             for k, cs in per_kernel.items()}
     k0 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<0"))
     k2 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<2"))
-    k3 = summ["K3 rq_hist_kernel"]
-    kb = summ["K3 rq_bracket_kernel (the one pass over the slab)"]
+    kb = summ["K3 rq_count_kernel<16,true> (the one pass over the slab)"]
     m = lambda k, c: k[c]["mean_per_launch"]
     wave_months = (PATHS_COUNT / 64) * MONTHS_COUNT
     stat_rows = list(csv.DictReader(open(stats)))
@@ -69,24 +71,29 @@ def main(src: str, dst: str) -> None:
         "K1_full_WRITE_SIZE_bytes_per_launch": m(k2, "WRITE_SIZE") * 1024,
         "K1_full_algorithmic_write_bytes": alg_full,
         "K1_full_write_efficiency_algorithmic_over_measured": alg_full / (m(k2, "WRITE_SIZE") * 1024),
-        "K3_hist_FETCH_SIZE_x2_bytes_per_launch_mean": 2 * m(k3, "FETCH_SIZE") * 1024,
         "K3_bracket_slab_bytes_algorithmic": 8 * PATHS_FULL * (2 * T_FULL + RY_FULL),
         "K3_bracket_FETCH_SIZE_x2_bytes_per_launch": 2 * m(kb, "FETCH_SIZE") * 1024,
         "K3_bracket_WRITE_SIZE_bytes_per_launch": m(kb, "WRITE_SIZE") * 1024,
     }
-    kb_ms = next(float(r["AverageNs"]) for r in stat_rows if "rq_bracket_kernel" in r["Name"]) / 1e6
+    kb_ms = next(float(r["AverageNs"]) for r in stat_rows if "rq_count_kernel<16, true>" in r["Name"]) / 1e6
+    k3_names = ("rq_tiny", "rq_count_kernel", "rq_refine", "rq_collect", "rq_select", "rq_hist", "rq_cand", "rq_scan", "rq_init", "rq_flag")
+    k3_rows = [r for r in stat_rows if any(t in r["Name"] for t in k3_names)]
+    calls = max(1, min(int(r["Calls"]) for r in stat_rows if "rq_count_kernel<16, true>" in r["Name"]))
+    derived["K3_launches_per_call"] = sum(int(r["Calls"]) for r in k3_rows) / calls
+    derived["K3_kernel_ms_per_call_sum"] = sum(float(r["TotalDurationNs"]) for r in k3_rows) / calls / 1e6
+    derived["K3_valu_busy_slab_pass"] = (m(kb, "SQ_ACTIVE_INST_VALU") * 4 / (1024 * m(kb, "GRBM_GUI_ACTIVE") / 8)) if "SQ_ACTIVE_INST_VALU" in kb else None
     derived["K3_bracket_avg_ms_from_kernel_stats"] = kb_ms
     derived["K3_bracket_achieved_TBps"] = derived["K3_bracket_slab_bytes_algorithmic"] / (kb_ms * 1e-3) / 1e12
     derived["K3_bracket_traffic_over_algorithmic"] = (derived["K3_bracket_FETCH_SIZE_x2_bytes_per_launch"] +
                                                         derived["K3_bracket_WRITE_SIZE_bytes_per_launch"]) / derived["K3_bracket_slab_bytes_algorithmic"]
     json.dump({
-        "command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "
+        "command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-s60 "
                    "(separate passes: SQ, SQ instruction mix, FETCH_SIZE, WRITE_SIZE; tools/collect_profiles.sh)",
         "note": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM)",
         "kernels": summ, "derived": derived,
     }, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     json.dump({
-        "round": 1, "source": os.path.join(dst, "pmc_summary.json"),
+        "round": 2, "source": os.path.join(dst, "pmc_summary.json"),
         "path_kernel_count_only_bytes_per_launch": derived["K1_count_hbm_bytes_per_launch"],
         "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of 1e6 paths; the algorithmic traffic of the count-only kernel "
                 "is ~3907 workgroups x (2 + <=102) 8-byte atomics",
