@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCR_ABI_VERSION 4
+#define MCR_ABI_VERSION 5
 #define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
 #define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */
@@ -302,6 +302,23 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
                       const double* q, int32_t n_q, double* out, uint64_t* counts,
                       void* scratch, int device, void* hip_stream);
 int mcr_row_quantiles_last_fallback_rows(void);
+/*
+ * The bracketed route for rows SHARDED across GPUs (rank r holds n_local of the n_total entries of every row; the
+ * trajectories never move).  Between its stages the library calls `reduce(ctx, device_buf, count, dtype)`, which
+ * must SUM the `count` elements of `device_buf` (MCR_DT_I32: int32, MCR_DT_I64: int64; always inside `scratch`)
+ * across all ranks, in place, ordered after the work already enqueued on hip_stream (an RCCL all-reduce on that stream,
+ * or a synchronising host implementation), and return 0.  About ten such calls per invocation, the largest the two
+ * sub-histogram blocks (n_rows * 64 KiB) and the cell lists (n_rows * 96 KiB).  Every rank must call with the same
+ * n_rows, n_total, q; every rank returns the same exact quantiles.  Needs rank 0 to hold >= 4096 entries, world <= 64,
+ * fewer than 16 quantiles: otherwise MCR_ERR_UNSUPPORTED (use the stepwise radix select above).  Synchronises
+ * hip_stream once.  scratch: mcr_row_quantiles_scratch_bytes(n_rows, n_q, n_local).
+ */
+#define MCR_DT_I32 0
+#define MCR_DT_I64 1
+typedef int (*mcr_reduce_fn)(void* ctx, void* device_buf, int64_t count, int32_t dtype);
+int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int64_t n_total,
+                              const double* q, int32_t n_q, double* out, uint64_t* counts, void* scratch, int32_t rank,
+                              int32_t world, mcr_reduce_fn reduce, void* reduce_ctx, int device, void* hip_stream);
 
 /*
  * Histogram of final balances over the successful cohort (the CLI's 100-bin chart,

@@ -12,7 +12,7 @@ import os
 import threading
 from typing import Optional
 
-MCR_ABI_VERSION = 4
+MCR_ABI_VERSION = 5
 MCR_MAX_STREAMS = 16
 MCR_N_COUNTERS = 2
 MCR_N_STAT_ROWS = 4
@@ -49,6 +49,11 @@ _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_MATH_SINCOS: (1, 2),
     MCR_HELPER_MATH_DIV_PATH: (2, 1),
 }
+
+
+#: include/mcr.h: mcr_reduce_fn — int (*)(void* ctx, void* device_buf, int64_t count, int32_t dtype)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+MCR_DT_I32, MCR_DT_I64 = 0, 1
 
 
 class McrStream(C.Structure):
@@ -182,6 +187,7 @@ ABI_SYMBOLS = (
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
     "mcr_row_quantiles_last_fallback_rows",
+    "mcr_row_quantiles_sharded",
     "mcr_row_quantiles_reduce_block",
     "mcr_row_quantiles_begin",
     "mcr_row_quantiles_hist",
@@ -263,6 +269,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.mcr_row_quantiles.argtypes = [
         C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+    ]
+    lib.mcr_row_quantiles_sharded.restype = C.c_int
+    lib.mcr_row_quantiles_sharded.argtypes = [
+        C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int32, C.c_int32, REDUCE_FN, C.c_void_p, C.c_int, C.c_void_p,
     ]
     lib.mcr_row_quantiles_reduce_block.restype = C.c_int64
     lib.mcr_row_quantiles_reduce_block.argtypes = [C.c_int32, P(C.c_int64)]

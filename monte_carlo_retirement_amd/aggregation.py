@@ -9,6 +9,7 @@ torch tensors are device-memory handles only; all arithmetic is in the HIP kerne
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -54,7 +55,7 @@ def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0, reduce_cou
     import torch
 
     if reduce_counts is not None:
-        return _row_quantiles_sharded(rows, int(n), qs, reduce_counts, int(n_total if n_total is not None else n))
+        return _row_quantiles_sharded(rows, int(n), qs, reduce_counts, int(n_total if n_total is not None else n), scratch_owner)
 
     assert rows.is_cuda and rows.dtype == torch.float64 and rows.dim() == 2 and rows.stride(1) == 1
     lib = N.load_library()
@@ -99,8 +100,15 @@ def last_fallback_rows() -> int:
     return int(N.load_library().mcr_row_quantiles_last_fallback_rows())
 
 
-def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int):
+#: rows sharded over ranks take the bracketed single-pass route from this many entries per row IN TOTAL (below it the
+#: 4-read radix select is as fast); every shard must hold at least _SHARD_MIN_LOCAL entries (the first sample is rank 0's)
+_SHARDED_BRACKET_MIN_TOTAL = 1 << 21
+_SHARD_MIN_LOCAL = 65536
+
+
+def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int, scratch_owner=None):
     import torch
+    import torch.distributed as dist
 
     assert rows.is_cuda and rows.dtype == torch.float64 and rows.dim() == 2 and rows.stride(1) == 1
     lib = N.load_library()
@@ -108,16 +116,53 @@ def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int):
     q = _pandas_q(qs)
     dev = rows.device
     di = dev.index or 0
-    out = torch.empty((n_rows, len(q)), dtype=torch.float64, device=dev)
-    counts = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+    res = torch.empty(n_rows * (len(q) + 1), dtype=torch.float64, device=dev)
+    out, counts = res[:n_rows * len(q)], res[n_rows * len(q):]
     nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q), n_local))
     if nbytes <= 0:
         raise ValueError("unsupported number of rows / quantiles")
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    scratch = _scratch(scratch_owner, nbytes, dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def unpack():
+        host = res.cpu().numpy()
+        return host[:n_rows * len(q)].reshape(n_rows, len(q)), host[n_rows * len(q):].view(np.uint64).astype(np.int64)
+
+    # Route: the same on every rank (it depends on n_total and on the SMALLEST shard, agreed through one tiny reduction)
+    grouped = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if grouped else (0, 1)
+    floor = int(os.environ.get("MCR_RQ_SHARDED_BRACKET_MIN_N", _SHARDED_BRACKET_MIN_TOTAL))
+    use_bracket = grouped and n_total >= floor and 2 * len(q) < 32 and world <= 64
+    if use_bracket:
+        short = torch.tensor([1 if n_local < min(_SHARD_MIN_LOCAL, floor) else 0], dtype=torch.int32, device=dev)
+        reduce_counts(short)
+        use_bracket = int(short.item()) == 0
+    if use_bracket:
+        base = scratch.data_ptr()
+        errors = []
+
+        def reduce(_ctx, ptr, count, dtype):
+            try:
+                width, tdt = (4, torch.int32) if dtype == N.MCR_DT_I32 else (8, torch.int64)
+                off = int(ptr) - base
+                reduce_counts(scratch[off:off + int(count) * width].view(tdt))
+                return 0
+            except Exception as exc:  # never let an exception cross the C boundary
+                errors.append(exc)
+                return 1
+
+        cb = N.REDUCE_FN(reduce)
+        rc = lib.mcr_row_quantiles_sharded(
+            rows.data_ptr(), int(rows.stride(0)), n_rows, n_local, n_total, q.ctypes.data, len(q), out.data_ptr(),
+            counts.data_ptr(), scratch.data_ptr(), rank, world, cb, None, di, stream)
+        if errors:
+            raise errors[0]
+        N.check(rc, "mcr_row_quantiles_sharded")
+        return unpack()
+
     n_words = C.c_int64()
     off = int(lib.mcr_row_quantiles_reduce_block(n_rows, C.byref(n_words)))
     block = scratch[off:off + 4 * n_words.value].view(torch.int32)  # the dense counter block to sum across ranks
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     N.check(lib.mcr_row_quantiles_begin(scratch.data_ptr(), n_rows, di, stream), "mcr_row_quantiles_begin")
     for p in range(8):
         N.check(lib.mcr_row_quantiles_hist(rows.data_ptr(), int(rows.stride(0)), n_rows, n_local, len(q), p,
@@ -125,7 +170,7 @@ def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int):
         reduce_counts(block)
         N.check(lib.mcr_row_quantiles_scan(n_rows, n_total, q.ctypes.data, len(q), p, out.data_ptr(), counts.data_ptr(),
                                            scratch.data_ptr(), di, stream), "mcr_row_quantiles_scan")
-    return out.cpu().numpy(), counts.cpu().numpy()
+    return unpack()
 
 
 def success_histogram(values, success, n_bins: int = 100, value_range: Optional[Tuple[float, float]] = None,

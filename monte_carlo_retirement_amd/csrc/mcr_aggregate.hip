@@ -488,8 +488,8 @@ __device__ void rq_make_intervals(RqBracket& B, const unsigned long long* lo, co
 // per quantile, the sample's order statistics kRqCoarseSigmas binomial standard deviations either side of the
 // quantile's rank.  A one-key interval (lo == hi: the bracket sits inside one giant tie) stays a one-key interval
 // all the way down and needs no candidates.
-__global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict__ rows, int64_t row_stride, const RqArgs args,
-                                                      RqBracket* br1, unsigned int* hist1, unsigned int* fb_count) {
+__global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n_avail,
+                                                      const RqArgs args, RqBracket* br1, unsigned int* hist1, unsigned int* fb_count) {
     __shared__ unsigned long long keys[kRqTiny];
     __shared__ unsigned long long qlo[kRqMaxQ], qhi[kRqMaxQ];
     __shared__ unsigned int nan_n, open_lo, open_hi;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
     unsigned long long key[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const double x = r[e * 1024 + t];
+        const double x = (int64_t)(e * 1024 + t) < n_avail ? r[e * 1024 + t] : __longlong_as_double(0x7ff8000000000000LL);
         const bool isnan_x = x != x;
         key[e] = isnan_x ? ~0ull : key_of(x);        // (~0 is not the key of any non-NaN double: NaNs sort last)
         my_nan += isnan_x ? 1u : 0u;
@@ -793,7 +793,9 @@ __global__ __launch_bounds__(256) void rq_refine_kernel(int64_t m, const RqArgs 
         }
     }
     __syncthreads();
-    const unsigned long long mv = (unsigned long long)m - B1.n_nan;   // non-NaN entries of the sample
+    unsigned long long mv;   // non-NaN entries of the sample (m <= 0: a sample pooled over ranks, its size is the sum of the counts)
+    if (m > 0) mv = (unsigned long long)m - B1.n_nan;
+    else { mv = 0ull; for (int k = 0; k <= 2 * nb; ++k) mv += B1.pos_count[k]; }
     if (t < args.n_q && !miss) {
         if (mv < 1024ull) {
             miss = 1u;
@@ -874,7 +876,8 @@ struct RqResolved {   // lives in LDS
 };
 // All threads of a 1024-thread workgroup.  pre: [kRqMaxQ][bins] u32 (LDS), want: [kRqMaxQ][bins] u8 (LDS) or nullptr.
 __device__ void rq_resolve_row(RqResolved& R, unsigned int* pre, unsigned char* want, int64_t n, const RqArgs& args,
-                               const RqBracket& B, const unsigned int* h2, int sub_bits, unsigned int cand_cap, unsigned int list_cap) {
+                               const RqBracket& B, const unsigned int* h2, int sub_bits, unsigned int cand_cap, unsigned int list_cap,
+                               const unsigned int* cand_total /* rows sharded over ranks: the candidates of ALL ranks, else nullptr */) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nb = B.n_intervals;
     const int bins = 1 << sub_bits;
@@ -895,7 +898,8 @@ __device__ void rq_resolve_row(RqResolved& R, unsigned int* pre, unsigned char* 
             if (B.lo[b] != B.hi[b]) inside += R.upto[b] - R.below[b];           // one-key intervals stored nothing
         }
         R.m_valid = (unsigned long long)n - B.n_nan;
-        if (B.cand_count > cand_cap || inside != (unsigned long long)B.cand_count) R.fb = 1u;
+        const unsigned long long stored = cand_total ? (unsigned long long)*cand_total : (unsigned long long)B.cand_count;
+        if (B.cand_count > cand_cap || inside != stored) R.fb = 1u;
     }
     __syncthreads();
     const unsigned long long m = R.m_valid;
@@ -951,16 +955,25 @@ __device__ void rq_resolve_row(RqResolved& R, unsigned int* pre, unsigned char* 
 
 __global__ __launch_bounds__(1024) void rq_collect_kernel(int64_t n, const RqArgs args, const RqBracket* br2, const unsigned int* hist2,
                                                          int sub_bits, const double* __restrict__ cand, unsigned int cand_cap,
-                                                         unsigned int list_cap, unsigned long long* glist, unsigned int* gfill) {
+                                                         unsigned int list_cap, unsigned long long* glist, unsigned int* gfill,
+                                                         const unsigned int* cand_total, const unsigned int* lsz, int rank, int n_rows) {
     extern __shared__ __align__(16) unsigned char dyn[];     // pre u32 [kRqMaxQ][bins] | want u8 [kRqMaxQ][bins]
     __shared__ RqResolved R;
+    __shared__ unsigned int cell_base[kRqMaxT];               // rows sharded over ranks: where this rank's keys start in each cell
     const int row = blockIdx.y, t = threadIdx.x;
     const RqBracket& B = br2[row];
     const int bins = 1 << sub_bits;
     unsigned int* pre = reinterpret_cast<unsigned int*>(dyn);
     unsigned char* want = dyn + (size_t)kRqMaxQ * bins * sizeof(unsigned int);
-    rq_resolve_row(R, pre, want, n, args, B, hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins, sub_bits, cand_cap, list_cap);
+    rq_resolve_row(R, pre, want, n, args, B, hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins, sub_bits, cand_cap, list_cap,
+                   cand_total ? cand_total + row : nullptr);
     if (R.fb || R.m_valid == 0ull || R.n_cells == 0) return;
+    if (t < kRqMaxT) {   // (lsz[r][row][c] = keys of cell c that rank r holds: the ranks before this one come first)
+        unsigned int base = 0u;
+        if (lsz) for (int r = 0; r < rank; ++r) base += lsz[((size_t)r * n_rows + row) * kRqMaxT + t];
+        cell_base[t] = base;
+    }
+    __syncthreads();
     const int nb = B.n_intervals;
     const double* crow = cand + (size_t)row * cand_cap;        // 16-byte aligned: cand_cap is even
     unsigned long long* lrow = glist + (size_t)row * list_cap;
@@ -984,7 +997,7 @@ __global__ __launch_bounds__(1024) void rq_collect_kernel(int64_t n, const RqArg
         }
         const unsigned int c = want[b * bins + rq_sub_bin(k, x, R.ivlo[b], R.ivshift[b], R.ivxlo[b], R.ivinvw[b], bins)];
         if (c != 255u) {
-            const unsigned int slot = atomicAdd(&frow[c], 1u);
+            const unsigned int slot = cell_base[c] + atomicAdd(&frow[c], 1u);
             if (slot < R.cell_size[c]) lrow[R.cell_off[c] + slot] = k;
         }
     };
@@ -1015,7 +1028,7 @@ __global__ __launch_bounds__(1024) void rq_select_kernel(int64_t n, const RqArgs
                                                         int sub_bits, unsigned int cand_cap, unsigned int list_cap,
                                                         const unsigned long long* glist, const unsigned int* gfill, double* out,
                                                         unsigned long long* counts, unsigned int* row_fallback, unsigned int* fb_list,
-                                                        unsigned int* fb_count) {
+                                                        unsigned int* fb_count, const unsigned int* cand_total) {
     extern __shared__ __align__(16) unsigned char dyn[];     // pre u32 [kRqMaxQ][bins] | list u64 [list_cap]
     __shared__ RqResolved R;
     __shared__ unsigned int whist[kRqWaves * 256];
@@ -1024,7 +1037,8 @@ __global__ __launch_bounds__(1024) void rq_select_kernel(int64_t n, const RqArgs
     const int bins = 1 << sub_bits;
     unsigned int* pre = reinterpret_cast<unsigned int*>(dyn);
     unsigned long long* list = reinterpret_cast<unsigned long long*>(dyn + (size_t)kRqMaxQ * bins * sizeof(unsigned int));
-    rq_resolve_row(R, pre, nullptr, n, args, B, hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins, sub_bits, cand_cap, list_cap);
+    rq_resolve_row(R, pre, nullptr, n, args, B, hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins, sub_bits, cand_cap, list_cap,
+                   cand_total ? cand_total + row : nullptr);
     const int nt = 2 * args.n_q;
     const unsigned long long m = R.m_valid;
     if (!R.fb && m > 0) {   // every cell must have received exactly its keys
@@ -1098,6 +1112,49 @@ __global__ __launch_bounds__(1024) void rq_select_kernel(int64_t n, const RqArgs
         if (g >= 0.5) r = b - diff * (1.0 - g);
         out[(size_t)row * args.n_q + t] = r;
     }
+}
+
+// ---- rows sharded over ranks: what crosses ranks between the stages of the bracketed route --------------------
+// Dense counter block of one level: per row pos_count[2 * kRqMaxQ + 1] | n_nan | candidates stored | "my candidate
+// buffer overflowed".  Every rank packs its own, the caller sums the block (and the level's sub-histograms) across
+// ranks, every rank unpacks the sums.
+constexpr int kRqCntWords = 2 * kRqMaxQ + 4;
+constexpr int kRqMaxWorld = 64;
+__global__ void rq_pack_kernel(const RqBracket* br, unsigned long long* cnt, int n_rows, unsigned int cand_cap) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const RqBracket& B = br[row];
+    unsigned long long* c = cnt + (size_t)row * kRqCntWords;
+    for (int k = 0; k <= 2 * kRqMaxQ; ++k) c[k] = B.pos_count[k];
+    c[2 * kRqMaxQ + 1] = B.n_nan;
+    c[2 * kRqMaxQ + 2] = B.cand_count;
+    c[2 * kRqMaxQ + 3] = B.cand_count > cand_cap ? 1ull : 0ull;
+}
+__global__ void rq_unpack_kernel(RqBracket* br, const unsigned long long* cnt, unsigned int* cand_total, int n_rows) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    RqBracket& B = br[row];
+    const unsigned long long* c = cnt + (size_t)row * kRqCntWords;
+    for (int k = 0; k <= 2 * kRqMaxQ; ++k) B.pos_count[k] = c[k];
+    B.n_nan = c[2 * kRqMaxQ + 1];
+    cand_total[row] = c[2 * kRqMaxQ + 2] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)c[2 * kRqMaxQ + 2];
+    if (c[2 * kRqMaxQ + 3]) B.fallback = 1u;           // some rank's candidates overflowed: every rank drops the row together
+}
+// After the global counts are in: the cells of every row (identical on all ranks) and how many keys of each THIS rank
+// holds (from its own sub-histograms, kept aside before they were summed).
+__global__ __launch_bounds__(1024) void rq_cells_kernel(int64_t n, const RqArgs args, const RqBracket* br2, const unsigned int* hist2,
+                                                       const unsigned int* hist_local, int sub_bits, unsigned int cand_cap,
+                                                       unsigned int list_cap, const unsigned int* cand_total, unsigned int* lsz,
+                                                       int rank, int n_rows) {
+    extern __shared__ __align__(16) unsigned char dyn[];     // pre u32 [kRqMaxQ][bins]
+    __shared__ RqResolved R;
+    const int row = blockIdx.x, t = threadIdx.x;
+    rq_resolve_row(R, reinterpret_cast<unsigned int*>(dyn), nullptr, n, args, br2[row], hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins,
+                   sub_bits, cand_cap, list_cap, cand_total + row);
+    if (R.fb || R.m_valid == 0ull) return;
+    if (t < R.n_cells)
+        lsz[((size_t)rank * n_rows + row) * kRqMaxT + t] =
+            hist_local[(size_t)row * kRqMaxQ * kRqMaxSubBins + (size_t)R.cell_b[t] * kRqMaxSubBins + R.cell_s[t]];
 }
 
 // ---- K2: successful-cohort min/max and equal-width histogram ------------------------------------
@@ -1250,6 +1307,10 @@ struct RqLayout {
     unsigned int* hist2;
     unsigned long long* glist;  // [n_rows][kRqListCap]: keys of the wanted cells
     unsigned int* gfill;        // [n_rows][kRqMaxT]: keys appended per cell
+    unsigned long long* cnt;    // rows sharded over ranks: [n_rows][kRqCntWords] counter block that is summed across ranks
+    unsigned int* cand_total;   //   [n_rows] candidates of all ranks
+    unsigned int* lsz;          //   [kRqMaxWorld][n_rows][kRqMaxT] keys of every cell held by every rank
+    size_t glist_bytes, gfill_words, hist_words, br_bytes, cnt_words, lsz_words;
     unsigned int* row_fallback;
     unsigned int* fb_list;      // rows that take the full radix passes, and how many
     unsigned int* fb_count;
@@ -1271,8 +1332,17 @@ static RqLayout rq_layout(void* scratch, int32_t n_rows, int64_t n = 0) {
     const size_t hist_bytes = (size_t)n_rows * kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int);
     const size_t off_gl = rq_align16(off_h + 2 * hist_bytes);
     const size_t off_gf = rq_align16(off_gl + (size_t)n_rows * kRqListCap * sizeof(unsigned long long));
-    const size_t off_bc = rq_align16(off_gf + (size_t)n_rows * kRqMaxT * sizeof(unsigned int));
+    const size_t off_cn = rq_align16(off_gf + (size_t)n_rows * kRqMaxT * sizeof(unsigned int));
+    const size_t off_ct = rq_align16(off_cn + (size_t)n_rows * kRqCntWords * sizeof(unsigned long long));
+    const size_t off_ls = rq_align16(off_ct + (size_t)n_rows * sizeof(unsigned int));
+    const size_t off_bc = rq_align16(off_ls + (size_t)kRqMaxWorld * n_rows * kRqMaxT * sizeof(unsigned int));
     L.total_bytes = off_bc + (size_t)n_rows * (size_t)rq_bracket_cand_cap(n) * sizeof(double);
+    L.glist_bytes = (size_t)n_rows * kRqListCap * sizeof(unsigned long long);
+    L.gfill_words = (size_t)n_rows * kRqMaxT;
+    L.hist_words = (size_t)n_rows * kRqMaxQ * kRqMaxSubBins;
+    L.br_bytes = (size_t)n_rows * sizeof(RqBracket);
+    L.cnt_words = (size_t)n_rows * kRqCntWords;
+    L.lsz_words = (size_t)kRqMaxWorld * n_rows * kRqMaxT;
     char* base = (char*)scratch;
     L.st = (RqRow*)base;
     L.hist = (unsigned int*)(base + L.reduce_offset);
@@ -1287,6 +1357,9 @@ static RqLayout rq_layout(void* scratch, int32_t n_rows, int64_t n = 0) {
     L.hist2 = (unsigned int*)(base + off_h + hist_bytes);
     L.glist = (unsigned long long*)(base + off_gl);
     L.gfill = (unsigned int*)(base + off_gf);
+    L.cnt = (unsigned long long*)(base + off_cn);
+    L.cand_total = (unsigned int*)(base + off_ct);
+    L.lsz = (unsigned int*)(base + off_ls);
     L.bcand = (double*)(base + off_bc);
     return L;
 }
@@ -1295,6 +1368,36 @@ static int rq_check(const void* scratch, int32_t n_rows, int64_t n_local, int32_
     if (!scratch || n_rows <= 0 || n_rows > 65535 || n_q <= 0 || n_q > kRqMaxQ) { set_error("bad row-quantile arguments"); return MCR_ERR_INVALID_ARG; }
     if (n_local < 0 || n_local >= ((int64_t)1 << 32)) { set_error("n must be < 2^32 per row"); return MCR_ERR_INVALID_ARG; }
     return MCR_OK;
+}
+
+// kernels whose dynamic LDS request can exceed the 64 KB default
+static void rq_opt_in_lds(int device) {
+    static thread_local int lds_opt_in_device = -1;
+    if (lds_opt_in_device == device) return;
+    const int big = 160 * 1024 - 24 * 1024;
+    (void)hipFuncSetAttribute((const void*)rq_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)rq_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)rq_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)rq_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipGetLastError();
+    lds_opt_in_device = device;
+}
+
+// One counting pass over the first `len` entries of every row.
+static void rq_count_pass(hipStream_t s, const double* rows, int64_t row_stride, int32_t n_rows, int64_t len, RqBracket* br,
+                          unsigned int* hist, int sub_bits, bool compact, bool small_p, double* bcand, unsigned int bcap) {
+    // slab pass: ~4096 workgroups in flight; sample pass: few per row — every workgroup flushes its sub-histograms
+    // (up to 1024 bins per interval) with global atomics, and the sample is only 1/32 of the slab
+    const int per_row = compact ? (4096 / n_rows > 0 ? 4096 / n_rows : 1) : (1024 / n_rows > 1 ? 1024 / n_rows : 2);
+    const int bx = grid_for(len > 0 ? len : 1, kRqBlock * 16, per_row);
+    const dim3 grid(bx, n_rows), block(kRqBlock);
+    const size_t lds = (size_t)(small_p ? 8 : 16) * ((size_t)1 << sub_bits) * sizeof(unsigned int);
+#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, bcand, bcap)
+    if (small_p) { if (compact) MCR_COUNT(16, true); else MCR_COUNT(16, false); }
+    else { if (compact) MCR_COUNT(32, true); else MCR_COUNT(32, false); }
+#undef MCR_COUNT
 }
 
 }  // namespace mcr
@@ -1448,22 +1551,10 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     std::memset(&a, 0, sizeof(a));
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
-    {   // kernels whose dynamic LDS request can exceed the 64 KB default
-        static thread_local int lds_opt_in_device = -1;
-        if (lds_opt_in_device != device) {
-            const int big = 160 * 1024 - 24 * 1024;
-            (void)hipFuncSetAttribute((const void*)rq_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)rq_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            (void)hipFuncSetAttribute((const void*)rq_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipGetLastError();
-            lds_opt_in_device = device;
-        }
-    }
+    rq_opt_in_lds(device);
     // (1) coarse brackets from the first kRqTiny entries of every row, sorted in LDS (paths are exchangeable; an
     //     unlucky or adversarial prefix only costs the affected rows the fallback below)
-    hipLaunchKernelGGL(rq_tiny_kernel, dim3(n_rows), dim3(1024), 0, s, rows, row_stride, a, L.br1, L.hist1, L.fb_count);
+    hipLaunchKernelGGL(rq_tiny_kernel, dim3(n_rows), dim3(1024), 0, s, rows, row_stride, n, a, L.br1, L.hist1, L.fb_count);
     // (2) the counting pass over a sample (the first n/32 entries), (3) fine brackets from its counts
     int64_t m = n / 32;
     if (m < 65536) m = 65536;
@@ -1473,16 +1564,7 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     const bool small_p = 2 * n_q < 16;                        // bound table: the next power of two above 2 * (intervals <= quantiles)
     const unsigned int bcap = rq_bracket_cand_cap(n);
     auto count_pass = [&](int64_t len, RqBracket* br, unsigned int* hist, int sub_bits, bool compact) {
-        // slab pass: ~4096 workgroups in flight; sample pass: few per row — every workgroup flushes its sub-histograms
-        // (up to 1024 bins per interval) with global atomics, and the sample is only 1/32 of the slab
-        const int per_row = compact ? (4096 / n_rows > 0 ? 4096 / n_rows : 1) : (1024 / n_rows > 1 ? 1024 / n_rows : 2);
-        const int bx = grid_for(len, kRqBlock * 16, per_row);
-        const dim3 grid(bx, n_rows), block(kRqBlock);
-        const size_t lds = (size_t)(small_p ? 8 : 16) * ((size_t)1 << sub_bits) * sizeof(unsigned int);
-#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, L.bcand, bcap)
-        if (small_p) { if (compact) MCR_COUNT(16, true); else MCR_COUNT(16, false); }
-        else { if (compact) MCR_COUNT(32, true); else MCR_COUNT(32, false); }
-#undef MCR_COUNT
+        rq_count_pass(s, rows, row_stride, n_rows, len, br, hist, sub_bits, compact, small_p, L.bcand, bcap);
     };
     count_pass(m, L.br1, L.hist1, kRqCoarseSubBits, false);
     hipLaunchKernelGGL(rq_refine_kernel, dim3(n_rows), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), s, m, a, L.br1,
@@ -1495,10 +1577,10 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
         const unsigned int list_cap = sub_bits2 == 8 ? kRqListCap : kRqListCap / 2;
         const int per_row = n >= ((int64_t)1 << 23) ? 8 : (n >= ((int64_t)1 << 21) ? 4 : 2);   // a few MB of candidates per row
         hipLaunchKernelGGL(rq_collect_kernel, dim3(per_row, n_rows), dim3(1024), (size_t)kRqMaxQ * bins * 5, s, n, a, L.br2, L.hist2, sub_bits2,
-                           L.bcand, bcap, list_cap, L.glist, L.gfill);
+                           L.bcand, bcap, list_cap, L.glist, L.gfill, (const unsigned int*)nullptr, (const unsigned int*)nullptr, 0, (int)n_rows);
         const size_t lds = (size_t)kRqMaxQ * bins * sizeof(unsigned int) + (size_t)list_cap * sizeof(unsigned long long);
         hipLaunchKernelGGL(rq_select_kernel, dim3(n_rows), dim3(1024), lds, s, n, a, L.br2, L.hist2, sub_bits2, bcap, list_cap, L.glist, L.gfill,
-                           out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count);
+                           out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count, (const unsigned int*)nullptr);
     }
     // (6) rows the brackets could not decide (a target outside its bracket, candidates overflowing on a wide tie
     //     that straddles a bracket end, a sample without data) take the full passes.  How many is only known on the
@@ -1517,6 +1599,110 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     }
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "bracketed row quantiles");
+    return MCR_OK;
+}
+
+// The bracketed route for rows SHARDED over ranks (every rank holds n_local of the n_total entries of each row).  Same
+// stages as mcr_row_quantiles; between them the caller's `reduce` sums small blocks across ranks in place: the coarse
+// brackets of rank 0 (a sum in which the other ranks contribute zeros), the counter block and sub-histograms of each
+// counting pass, the per-rank cell sizes, the cell lists (disjoint slots: a sum is a gather) and their fill counts.
+// The slab never moves; every rank ends with the same exact quantiles.
+int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_rows, int64_t n_local, int64_t n_total,
+                              const double* q, int32_t n_q, double* out, uint64_t* counts, void* scratch, int32_t rank,
+                              int32_t world, mcr_reduce_fn reduce, void* reduce_ctx, int device, void* hip_stream) {
+    g_last_fallback_rows = -1;
+    MCR_ENTER_DEVICE(device);
+    int rc = rq_check(scratch, n_rows, n_local, n_q);
+    if (rc != MCR_OK) return rc;
+    if (!reduce || world < 1 || world > kRqMaxWorld || rank < 0 || rank >= world) { set_error("bad rank / world / reduce callback"); return MCR_ERR_INVALID_ARG; }
+    if (!q || !out || n_total <= 0 || n_total >= ((int64_t)1 << 32) || n_local > n_total || (n_local > 0 && (!rows || row_stride < n_local))) {
+        set_error("bad arguments");
+        return MCR_ERR_INVALID_ARG;
+    }
+    if (2 * n_q >= 32 || n_total < kRqTiny || (rank == 0 && n_local < kRqTiny)) {
+        set_error("shape not supported by the sharded bracketed route (use the stepwise radix select)");
+        return MCR_ERR_UNSUPPORTED;
+    }
+    for (int j = 0; j < n_q; ++j)
+        if (!(q[j] >= 0.0 && q[j] <= 1.0)) { set_error("quantile %d out of [0,1]", j); return MCR_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    const RqLayout L = rq_layout(scratch, n_rows, n_local);
+    RqArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_q = n_q;
+    for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
+    rq_opt_in_lds(device);
+    auto sum = [&](void* buf, size_t count, int32_t dtype, const char* what) -> int {
+        if (reduce(reduce_ctx, buf, (int64_t)count, dtype) != 0) { set_error("reduce callback failed (%s)", what); return MCR_ERR_HIP; }
+        return MCR_OK;
+    };
+    const int blocks = (n_rows + 255) / 256;
+    const unsigned int bcap = rq_bracket_cand_cap(n_local);
+    const bool small_p = 2 * n_q < 16;
+    const int sub_bits2 = n_total <= ((int64_t)1 << 24) ? 8 : 10;
+    hipError_t e = hipSuccess;
+    // (1) coarse brackets: rank 0's first sample decides for everybody
+    hipLaunchKernelGGL(rq_tiny_kernel, dim3(n_rows), dim3(1024), 0, s, rows, row_stride, n_local, a, L.br1, L.hist1, L.fb_count);
+    if (rank != 0) e = hipMemsetAsync(L.br1, 0, L.br_bytes, s);
+    if (e != hipSuccess) return hip_fail(e, "sharded quantiles");
+    if ((rc = sum(L.br1, L.br_bytes / 4, MCR_DT_I32, "coarse brackets")) != MCR_OK) return rc;
+    // (2) the sample is pooled: every rank counts a prefix of its own shard; (3) fine brackets, identical everywhere
+    int64_t m_total = n_total / 32;
+    if (m_total < 65536) m_total = 65536;
+    if (m_total > n_total) m_total = n_total;
+    int64_t m_local = (m_total + world - 1) / world;
+    if (m_local > n_local) m_local = n_local;
+    m_local &= ~(int64_t)1;
+    rq_count_pass(s, rows, row_stride, n_rows, m_local, L.br1, L.hist1, kRqCoarseSubBits, false, small_p, L.bcand, bcap);
+    hipLaunchKernelGGL(rq_pack_kernel, dim3(blocks), dim3(256), 0, s, L.br1, L.cnt, (int)n_rows, bcap);
+    if ((rc = sum(L.cnt, L.cnt_words, MCR_DT_I64, "sample counts")) != MCR_OK) return rc;
+    if ((rc = sum(L.hist1, L.hist_words, MCR_DT_I32, "sample sub-histograms")) != MCR_OK) return rc;
+    hipLaunchKernelGGL(rq_unpack_kernel, dim3(blocks), dim3(256), 0, s, L.br1, L.cnt, L.cand_total, (int)n_rows);
+    hipLaunchKernelGGL(rq_refine_kernel, dim3(n_rows), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), s, (int64_t)0, a,
+                       L.br1, L.hist1, L.br2, L.hist2, sub_bits2, L.gfill);
+    // (4) the one pass over the local slab; this rank's own sub-histograms are kept aside (hist1 is free again)
+    rq_count_pass(s, rows, row_stride, n_rows, n_local, L.br2, L.hist2, sub_bits2, true, small_p, L.bcand, bcap);
+    e = hipMemcpyAsync(L.hist1, L.hist2, L.hist_words * sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return hip_fail(e, "sharded quantiles");
+    hipLaunchKernelGGL(rq_pack_kernel, dim3(blocks), dim3(256), 0, s, L.br2, L.cnt, (int)n_rows, bcap);
+    if ((rc = sum(L.cnt, L.cnt_words, MCR_DT_I64, "slab counts")) != MCR_OK) return rc;
+    if ((rc = sum(L.hist2, L.hist_words, MCR_DT_I32, "slab sub-histograms")) != MCR_OK) return rc;
+    hipLaunchKernelGGL(rq_unpack_kernel, dim3(blocks), dim3(256), 0, s, L.br2, L.cnt, L.cand_total, (int)n_rows);
+    // (5) cells (identical everywhere) and how many of each cell's keys every rank holds -> where each rank writes
+    const size_t bins = (size_t)1 << sub_bits2;
+    const unsigned int list_cap = sub_bits2 == 8 ? kRqListCap : kRqListCap / 2;
+    const size_t lsz_used = (size_t)world * n_rows * kRqMaxT;
+    e = hipMemsetAsync(L.lsz, 0, lsz_used * sizeof(unsigned int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(L.glist, 0, L.glist_bytes, s);
+    if (e != hipSuccess) return hip_fail(e, "sharded quantiles");
+    hipLaunchKernelGGL(rq_cells_kernel, dim3(n_rows), dim3(1024), (size_t)kRqMaxQ * bins * sizeof(unsigned int), s, n_total, a, L.br2, L.hist2,
+                       L.hist1, sub_bits2, bcap, list_cap, L.cand_total, L.lsz, (int)rank, (int)n_rows);
+    if ((rc = sum(L.lsz, lsz_used, MCR_DT_I32, "cell sizes")) != MCR_OK) return rc;
+    const int per_row = n_local >= ((int64_t)1 << 23) ? 8 : (n_local >= ((int64_t)1 << 21) ? 4 : 2);
+    hipLaunchKernelGGL(rq_collect_kernel, dim3(per_row, n_rows), dim3(1024), (size_t)kRqMaxQ * bins * 5, s, n_total, a, L.br2, L.hist2, sub_bits2,
+                       L.bcand, bcap, list_cap, L.glist, L.gfill, L.cand_total, L.lsz, (int)rank, (int)n_rows);
+    if ((rc = sum(L.glist, L.glist_bytes / 8, MCR_DT_I64, "cell lists")) != MCR_OK) return rc;
+    if ((rc = sum(L.gfill, L.gfill_words, MCR_DT_I32, "cell fills")) != MCR_OK) return rc;
+    // (6) selection in LDS -> interpolation (every rank computes the same)
+    const size_t lds = (size_t)kRqMaxQ * bins * sizeof(unsigned int) + (size_t)list_cap * sizeof(unsigned long long);
+    hipLaunchKernelGGL(rq_select_kernel, dim3(n_rows), dim3(1024), lds, s, n_total, a, L.br2, L.hist2, sub_bits2, bcap, list_cap, L.glist, L.gfill,
+                       out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count, L.cand_total);
+    unsigned int n_fb = 0;
+    e = hipMemcpyAsync(&n_fb, L.fb_count, sizeof(n_fb), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "sharded bracketed row quantiles");
+    g_last_fallback_rows = (int)n_fb;
+    if (n_fb > 0) {   // the same rows on every rank: the distributed radix select, digit histograms summed after every pass
+        rc = mcr_row_quantiles_begin(scratch, n_rows, device, hip_stream);
+        for (int pass = 0; pass < 8 && rc == MCR_OK; ++pass) {
+            rc = rq_hist_step(rows, row_stride, n_rows, n_local, n_q, pass, scratch, device, hip_stream, /*track_minmax=*/0, L.fb_list, (int)n_fb);
+            if (rc == MCR_OK) rc = sum(L.hist, L.reduce_words, MCR_DT_I32, "digit histograms");
+            if (rc == MCR_OK) rc = rq_scan_step(n_rows, n_total, q, n_q, pass, out, counts, scratch, device, hip_stream, L.fb_list, (int)n_fb);
+        }
+        if (rc != MCR_OK) return rc;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "sharded bracketed row quantiles");
     return MCR_OK;
 }
 

@@ -48,6 +48,47 @@ def main():
     res["quantiles_equal"] = bool(np.array_equal(got, exp, equal_nan=True))
     res["counts_equal"] = counts.tolist() == (~np.isnan(slab)).sum(axis=1).tolist()
 
+    # ---- (1b) the same through the sharded BRACKETED route: rows of 2^22 entries in total (the default threshold) and, with
+    # the threshold lowered, rows with ties / NaNs / constants that must fall back together on every rank
+    n_big = 1 << 22
+    rb = np.random.default_rng(5)
+    big = np.empty((4, n_big))
+    big[0] = rb.lognormal(14, 1.2, n_big)
+    big[1] = np.where(rb.random(n_big) < 0.2, np.nan, rb.normal(4.0, 1.5, n_big))
+    big[2] = 1.0e6
+    big[3] = np.where(rb.random(n_big) < 0.015, 0.0, rb.lognormal(13, 0.8, n_big))
+    b0, bc = D.shard_range(n_big, rank, world)
+    bstride = (bc + 63) // 64 * 64
+    blocal = torch.full((4, bstride), 7.0, dtype=torch.float64, device="cuda")
+    blocal[:, :bc] = torch.as_tensor(big[:, b0:b0 + bc], device="cuda")
+    gb, cb_ = D.sharded_row_quantiles(blocal, bc, A.TRAJECTORY_QUANTILES)
+    res["bracket_route_taken"] = A.last_fallback_rows() == 0
+    res["bracket_quantiles_equal"] = bool(all(
+        np.array_equal(gb[r], np.quantile(big[r][~np.isnan(big[r])], A.TRAJECTORY_QUANTILES)) for r in range(4)))
+    res["bracket_counts_equal"] = cb_.tolist() == (~np.isnan(big)).sum(axis=1).tolist()
+    del blocal
+    os.environ["MCR_RQ_SHARDED_BRACKET_MIN_N"] = "100000"
+    n_mid = 400_003
+    rm = np.random.default_rng(9)
+    mid = np.empty((7, n_mid))
+    mid[0] = rm.lognormal(13, 1, n_mid)
+    mid[1] = np.where(rm.random(n_mid) < 0.4, np.nan, rm.normal(5, 2, n_mid))
+    mid[2] = np.where(rm.random(n_mid) < 0.65, 0.0, rm.lognormal(10, 2, n_mid))    # giant tie + tail
+    mid[3] = 60000.0
+    mid[4] = np.nan
+    mid[5] = rm.choice([1.0, 2.0, 3.0, 5.0, 8.0], n_mid)                            # few distinct values
+    mid[6] = np.arange(n_mid, dtype=float)                                          # sorted: the prefix samples are useless
+    m0, mc = D.shard_range(n_mid, rank, world)
+    mstride = (mc + 63) // 64 * 64
+    mlocal = torch.full((7, mstride), 7.0, dtype=torch.float64, device="cuda")
+    mlocal[:, :mc] = torch.as_tensor(mid[:, m0:m0 + mc], device="cuda")
+    gm, cm = D.sharded_row_quantiles(mlocal, mc, A.TRAJECTORY_QUANTILES)
+    res["bracket_fallback_rows"] = A.last_fallback_rows()
+    expm = pd.DataFrame(mid.T).quantile(list(A.TRAJECTORY_QUANTILES), axis=0).T.to_numpy()
+    res["bracket_mid_equal"] = bool(np.array_equal(gm, expm, equal_nan=True))
+    res["bracket_mid_counts"] = cm.tolist() == (~np.isnan(mid)).sum(axis=1).tolist()
+    del os.environ["MCR_RQ_SHARDED_BRACKET_MIN_N"]
+
     # ---- (2) sharded bands vs one process over the whole range
     with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
         cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3, initial_balance=20000.0, monthly_contribution=3000.0))
