@@ -12,7 +12,7 @@
  * build container (tests/golden/generate_golden.py) — same glibc `exp`, same IEEE
  * double arithmetic, no FMA contraction (-ffp-contract=off).  The reference's own
  * closed-form unit pins (tests/test_simulation_correctness.py:605-662, :335-361) are
- * replayed in tests/test_oracle_pins.py.
+ * replayed in tests/test_oracle_golden.py (helper KATs of tests/golden/helpers.json).
  *
  * RNG: the reference draws shocks with NumPy (SeedSequence -> PCG64 -> ziggurat,
  * simulation.py:457-458).  The engine's stream is Philox4x32-10 + Box-Muller, restated
