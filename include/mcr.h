@@ -26,6 +26,7 @@ extern "C" {
 
 #define MCR_ABI_VERSION 5
 #define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
+#define MCR_MAX_PROBE_CANDIDATES 32 /* candidates of one mcr_probe_months_rng call that can share their accumulation sweep */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
 #define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */
 
@@ -229,9 +230,12 @@ int mcr_run_batch_multi_host_rng(const mcr_params* p, const mcr_rng* rng, uint32
  * Search driver support (find_minimum_working_months, simulation.py:1138-1342): success counts of
  * SEVERAL candidate working-month counts over the same path range — what the reference obtains by
  * calling run_monte_carlo_simulations(candidate, num_simulations_search) once per candidate and taking
- * _success_probability of each summary (simulation.py:1186-1199).  One count-only launch per candidate,
- * forked onto internal HIP streams so the candidates share the GPU concurrently (a 50 000-path probe
- * fills under a fifth of the chip), joined back onto `hip_stream`; asynchronous like mcr_run_batch.
+ * _success_probability of each summary (simulation.py:1186-1199).  Philox stream, 2..32 distinct candidates: the
+ * accumulation months do not depend on the candidate under common random numbers (simulation.py:513-579), so ONE sweep
+ * runs them to the largest candidate and stores the state at the end of every candidate month, and ONE launch
+ * (grid.y = candidate) resumes every decumulation from its snapshot; the snapshots are a stream-ordered allocation
+ * (80 B per path and candidate).  Otherwise: one count-only launch per candidate, forked onto internal HIP streams
+ * so the candidates share the GPU concurrently, joined back onto `hip_stream`.  Asynchronous like mcr_run_batch.
  * counts: DEVICE uint64 [n_candidates][MCR_N_COUNTERS] = {successes, paths} per candidate (zeroed by
  * the call).  Common random numbers across candidates hold as in the reference (same path range, same
  * stream).

@@ -47,7 +47,14 @@ struct KernelIO {
     uint32_t entropy[MCR_MAX_ENTROPY_WORDS];
     uint64_t child_offset;
     const uint32_t* path_seeds;  // [n_paths] explicit seeds or nullptr
+    // search probes that share their accumulation phase (PHASE 1 / 2 of path_kernel; mcr_probe_months_rng)
+    double* snap;                    // [n_snap][kSnapFields][snap_stride] state at the end of month snap_months[c]
+    int64_t snap_stride;
+    int32_t n_snap;
+    int32_t snap_months[MCR_MAX_PROBE_CANDIDATES];   // ascending
+    int32_t cand_out[MCR_MAX_PROBE_CANDIDATES];      // PHASE 2: counter block of candidate c = counters + cand_out[c] * MCR_N_COUNTERS
 };
+constexpr int kSnapFields = 10;   // b1 b2 c1 c2 gacc1 gacc2 infl contrib | pre_fail | Philox carry words
 
 // NaN OUTPUT values travel as integer bit patterns (robust against any no-NaN math assumption: the
 // state machine itself never produces a NaN for valid scenarios).
@@ -60,8 +67,16 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.
 // INJ = true: shocks come from io.injected (the parity hook) instead of the RNG; only instantiated with MODE 2
 // (every output is null-checked), so the hot variants carry neither the injection branches nor their registers.
-template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false>
-__global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, const KernelIO io) {
+// PHASE 0: the whole path.  PHASE 1 / 2 split it at retirement for the search (simulation.py:1180-1194 re-simulates the
+// accumulation months for every probed candidate although, under common random numbers, they do not depend on it,
+// :513-579): PHASE 1 runs the accumulation once to the largest candidate and stores the state at the end of every
+// candidate month; PHASE 2 (grid.y = candidate) resumes each candidate's decumulation from its snapshot.
+template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0>
+__global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P_arg, const KernelIO io,
+                                                         const DevParams* __restrict__ cand_params) {
+    // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
+    // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
+    const DevParams& P = PHASE == 2 ? cand_params[blockIdx.y] : P_arg;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS: math tables (mcr_math.h), then the NumPy ziggurat tables OR (Philox stream) the [6][kBlock] stage of two
     // months' gross factors, [n_lock_slots][kBlock] doubles (frozen nominal stream amounts), then block counters
@@ -164,10 +179,32 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
     bool pre_fail = false;                     // :510
     int t_idx = 0;
     put_sample(t_idx++, P.initial_balance, 1.0);  // :490-492
+    const int wm = P.working_months;
+    // snapshot c, field f of local path li: snap[(c * kSnapFields + f) * snap_stride + li]
+    auto snap_at = [&](int c, int f) { return io.snap + ((size_t)c * kSnapFields + (size_t)f) * (size_t)io.snap_stride + (size_t)li; };
+    int snap_i = 0;
+    auto save_snapshot = [&]() {
+        if (valid) {
+            *snap_at(snap_i, 0) = b1; *snap_at(snap_i, 1) = b2; *snap_at(snap_i, 2) = c1; *snap_at(snap_i, 3) = c2;
+            *snap_at(snap_i, 4) = gacc1; *snap_at(snap_i, 5) = gacc2; *snap_at(snap_i, 6) = infl; *snap_at(snap_i, 7) = contrib;
+            *snap_at(snap_i, 8) = pre_fail ? 1.0 : 0.0;
+            store_bits(snap_at(snap_i, 9), ((unsigned long long)carry.w3 << 32) | (unsigned long long)carry.w2);
+        }
+        ++snap_i;
+    };
+    if (PHASE == 1) while (snap_i < io.n_snap && io.snap_months[snap_i] == 0) save_snapshot();
+    if (PHASE == 2) {
+        const int c = blockIdx.y;
+        b1 = *snap_at(c, 0); b2 = *snap_at(c, 1); c1 = *snap_at(c, 2); c2 = *snap_at(c, 3);
+        gacc1 = *snap_at(c, 4); gacc2 = *snap_at(c, 5); infl = *snap_at(c, 6); contrib = *snap_at(c, 7);
+        pre_fail = *snap_at(c, 8) != 0.0;
+        const unsigned long long cw = f64_bits(*snap_at(c, 9));
+        carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
+        if (wm & 1) begin_month(wm - 1);   // the pair of rows (wm - 1, wm) was staged during the accumulation: stage it again
+    }
 
     // ---- accumulation (:513-579): no lane leaves this loop early ----
-    const int wm = P.working_months;
-    for (int m = 1; m <= wm; ++m) {
+    for (int m = 1; m <= (PHASE == 2 ? 0 : wm); ++m) {
         if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) {  // :514-517 (wave-uniform: a scalar branch, not a select)
             asm volatile("");
             contrib *= P.contrib_growth_factor;
@@ -185,7 +222,9 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
+        if (PHASE == 1 && snap_i < io.n_snap && m == io.snap_months[snap_i]) save_snapshot();
     }
+    if (PHASE == 1) return;   // (every thread of the workgroup: nothing below is needed)
     const double start_balance = b1 + b2;  // :581
     const double infl_ret = infl;          // :582
     if (wm > 0 && wm % kMPY != 0) put_sample(t_idx++, start_balance, infl_ret);  // :590-594
@@ -330,11 +369,12 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P, cons
         atomicAdd(&blk[1 + (ry + 2) + done_years], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && io.out.counters) {
-        atomicAdd((unsigned long long*)&io.out.counters[MCR_CTR_SUCCESS], (unsigned long long)blk[0]);
+    uint64_t* ctr = io.out.counters ? io.out.counters + (PHASE == 2 ? (size_t)io.cand_out[blockIdx.y] * MCR_N_COUNTERS : 0) : nullptr;
+    if (threadIdx.x == 0 && ctr) {
+        atomicAdd((unsigned long long*)&ctr[MCR_CTR_SUCCESS], (unsigned long long)blk[0]);
         const uint64_t first = (uint64_t)blockIdx.x * kBlock;
         const uint64_t cnt = io.n_paths - first < (uint64_t)kBlock ? io.n_paths - first : (uint64_t)kBlock;
-        atomicAdd((unsigned long long*)&io.out.counters[MCR_CTR_PATHS], (unsigned long long)cnt);
+        atomicAdd((unsigned long long*)&ctr[MCR_CTR_PATHS], (unsigned long long)cnt);
     }
     if (want_bins) {
         for (int k = threadIdx.x; k < ry + 2; k += kBlock) {
@@ -691,7 +731,7 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
     // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
     // shocks (parity hook) always take the full-output variant, whose every store is null-checked
-#define MCR_LAUNCH(M, R, T, A, I) hipLaunchKernelGGL((path_kernel<M, R, T, A, I>), grid, block, lds, stream, d, io)
+#define MCR_LAUNCH(M, R, T, A, I) hipLaunchKernelGGL((path_kernel<M, R, T, A, I>), grid, block, lds, stream, d, io, (const DevParams*)nullptr)
 #define MCR_LAUNCH_T(M, R, I)                                                                      \
     do {                                                                                           \
         if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH(M, R, true, true, I); else MCR_LAUNCH(M, R, true, false, I); } \
@@ -781,6 +821,62 @@ ProbeFork* probe_fork(int device) {
 }
 }  // namespace
 
+// Several candidates over the same paths, Philox stream: ONE accumulation sweep to the largest candidate that stores the
+// state at the end of every candidate month (PHASE 1), then ONE launch whose grid.y is the candidate and which resumes
+// every decumulation from its snapshot (PHASE 2).  The candidates' parameter blocks (stream start months, horizon) go to
+// device memory; snapshots and blocks are stream-ordered allocations.  Counts are identical to one launch per candidate.
+static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
+                               const int32_t* working_months, int32_t n_cand, uint64_t* counts, hipStream_t stream) {
+    if (n_cand < 2 || n_paths == 0 || n_paths > ((uint64_t)1 << 31)) return MCR_ERR_UNSUPPORTED;
+    int order[MCR_MAX_PROBE_CANDIDATES];
+    for (int i = 0; i < n_cand; ++i) {
+        int k = i;
+        while (k > 0 && working_months[order[k - 1]] > working_months[i]) { order[k] = order[k - 1]; --k; }
+        order[k] = i;
+    }
+    for (int i = 1; i < n_cand; ++i)
+        if (working_months[order[i]] == working_months[order[i - 1]]) return MCR_ERR_UNSUPPORTED;   // duplicates: plain route
+    std::vector<DevParams> blocks((size_t)n_cand);
+    for (int i = 0; i < n_cand; ++i) {
+        const int rc = derive_params(p, working_months[order[i]], &blocks[(size_t)i]);
+        if (rc != MCR_OK) return rc;
+    }
+    const DevParams& top = blocks[(size_t)n_cand - 1];
+    const size_t lds = path_kernel_lds_bytes(top, false);
+    if (lds > 64 * 1024) return MCR_ERR_UNSUPPORTED;
+    KernelIO io;
+    std::memset(&io, 0, sizeof(io));
+    fill_io_rng(io, rng, nullptr);
+    io.stream_id = stream_id; io.path_begin = path_begin; io.n_paths = n_paths;
+    io.out.counters = counts;
+    io.n_snap = n_cand;
+    io.snap_stride = (int64_t)((n_paths + 63) / 64 * 64);
+    for (int i = 0; i < n_cand; ++i) { io.snap_months[i] = working_months[order[i]]; io.cand_out[i] = order[i]; }
+    const size_t snap_bytes = (size_t)n_cand * kSnapFields * (size_t)io.snap_stride * sizeof(double);
+    const size_t blocks_bytes = (size_t)n_cand * sizeof(DevParams);
+    void* mem = nullptr;
+    if (hipMallocAsync(&mem, snap_bytes + blocks_bytes, stream) != hipSuccess) { (void)hipGetLastError(); return MCR_ERR_UNSUPPORTED; }
+    io.snap = (double*)mem;
+    const DevParams* d_blocks = (const DevParams*)((char*)mem + snap_bytes);
+    hipError_t e = hipMemcpyAsync((char*)mem + snap_bytes, blocks.data(), blocks_bytes, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        const dim3 block(kBlock), g1((unsigned)((n_paths + kBlock - 1) / kBlock)), g2(g1.x, (unsigned)n_cand);
+#define MCR_PHASES(T, A)                                                                                          \
+        do {                                                                                                       \
+            hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 1>), g1, block, lds, stream, top, io, d_blocks);    \
+            hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2>), g2, block, lds, stream, top, io, d_blocks);    \
+        } while (0)
+        if (top.any_real_rate) { if (top.any_annual_tax) MCR_PHASES(true, true); else MCR_PHASES(true, false); }
+        else { if (top.any_annual_tax) MCR_PHASES(false, true); else MCR_PHASES(false, false); }
+#undef MCR_PHASES
+        e = hipGetLastError();
+    }
+    const hipError_t ef = hipFreeAsync(mem, stream);
+    if (e != hipSuccess) return hip_fail(e, "shared-prefix probe");
+    if (ef != hipSuccess) return hip_fail(ef, "shared-prefix probe (free)");
+    return MCR_OK;
+}
+
 int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_id, uint64_t path_begin,
                          uint64_t n_paths, const int32_t* working_months, int32_t n_candidates,
                          uint64_t* counts, int device, void* hip_stream) {
@@ -804,6 +900,10 @@ int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t strea
         std::memset(&o, 0, sizeof(o));
         o.counters = counts;
         return launch_paths(p, rng, stream_id, path_begin, n_paths, working_months[0], nullptr, &o, main);
+    }
+    if (rng->kind == MCR_RNG_PHILOX && n_candidates <= MCR_MAX_PROBE_CANDIDATES) {
+        const int prc = probe_shared_prefix(p, rng, stream_id, path_begin, n_paths, working_months, n_candidates, counts, main);
+        if (prc != MCR_ERR_UNSUPPORTED) return prc;     // (unsupported shape / allocation refused: one launch per candidate below)
     }
     ProbeFork* f = probe_fork(device);
     if (!f) { set_error("could not create probe streams"); return MCR_ERR_HIP; }
