@@ -312,6 +312,38 @@ def test_probe_many_equals_one_launch_per_candidate(rng):
     assert E.probe_months(params, r, sim._stream_id, 0, n, months[:3]).cpu().tolist() == expect[:3]
 
 
+@pytest.mark.parametrize("idx", [0, 6, 7, 8, 9])
+def test_shared_accumulation_probes_equal_separate_launches(idx):
+    """Philox stream, 2..32 distinct candidates: mcr_probe_months_rng runs ONE accumulation sweep that stores the state at
+    the end of every candidate month and ONE launch that resumes all decumulations (path_kernel PHASE 1 / 2).  The counts
+    must equal one full launch per candidate — across tax systems (annual-tax scenarios carry the pre-retirement failure
+    flag and the gain accumulators through the snapshot), stream start months that depend on the candidate, odd and even
+    months (half-used Philox pairs), candidate 0, unsorted order — and more than 32 candidates take the plain route."""
+    from monte_carlo_retirement_amd import engine as E
+
+    g = load_golden("paths_injected.json")[idx]
+    sim = RetirementMonteCarloSimulator(Config(**g["cfg"]), main_seed_override=4711)
+    sim.use_search_seeds()
+    n = 3000
+    params, r = sim._current_params(), sim._batch_rng(n)
+
+    def separately(months):
+        out = []
+        for m in months:
+            b = E.DeviceBatch(params, m, n, want="count")
+            b.launch(r, sim._stream_id, 5)
+            out.append(b.counters.cpu().tolist())
+        return out
+
+    for months in ([37, 0, 14, 13, 36, 1, 2, 3, 50, 49, 12, 24], list(range(20, 52)), [7, 9], list(range(0, 66, 2))):
+        got = E.probe_months(params, r, sim._stream_id, 5, n, months).cpu().tolist()
+        assert got == separately(months), (g["name"], months)
+    # the probabilities move with the candidate (the snapshots are not all the same state)
+    few = E.probe_months(params, r, sim._stream_id, 5, n, [0, 30, 60, 240])[:, 0].cpu().tolist()
+    assert all(c == n for c in [int(x) for x in E.probe_months(params, r, sim._stream_id, 5, n, [0, 30, 60, 240])[:, 1].cpu().tolist()])
+    assert len(set(few)) > 1 or g["name"].startswith("PRETAX")
+
+
 def test_batched_search_equals_one_probe_at_a_time():
     """find_minimum_working_months with candidate batches (the verification window in one call; bracket and
     bisection points evaluated ahead when they are free) returns exactly what strictly one launch per
