@@ -166,6 +166,22 @@ def main():
     shd = sim2.run_monte_carlo_simulations(wm, 700)
     res["class_replicated_equals_sharded"] = bool(rep[0].equals(shd[0]) and np.array_equal(rep[1].to_numpy(), shd[1].to_numpy(), equal_nan=True)
                                                   and rep[6] == shd[6] and rep[2] == shd[2])
+    # ---- (3b) no seed configured: rank 0's time-derived seed is used by every rank, so the shards belong to ONE run and
+    # the sampled columns are the ones that run's seed picks (advisor r1)
+    from monte_carlo_retirement_amd.simulation import _fold_seed_u64
+
+    ns = RetirementMonteCarloSimulator(Config(**dict(cfg.model_dump(by_alias=True), seed=None)))
+    ns.shard_min_paths = 0
+    ns.use_final_seeds()
+    ns_out = ns.run_monte_carlo_simulations(wm, 2000)
+    ns_whole = E.DeviceBatch(p, wm, 2000, want="full", device=0)
+    ns_whole.launch(_fold_seed_u64(ns.main_seed), 1, 0)
+    ns_pick = np.random.RandomState(ns.main_seed).choice(2000, size=5, replace=False)
+    res["unseeded_seed"] = int(ns.main_seed)
+    res["unseeded_samples_equal"] = bool(
+        np.array_equal(np.array(ns_out[2]), ns_whole.trajectory[:, :2000].cpu().numpy()[:, ns_pick].T)
+        and np.array_equal(ns_out[0]["Final Balance"].to_numpy(), ns_whole.summary["final_balance"].cpu().numpy()))
+
     # ---- (4) the compact response document of a large batch, from sharded batches: equal to one process's document
     from monte_carlo_retirement_amd import results as R
 

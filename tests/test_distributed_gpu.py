@@ -49,6 +49,7 @@ def test_sharded_quantiles_and_bands_equal_unsharded(tmp_path, world):
         assert r["class_probe_many_by_candidate"] and r["class_probe_many_by_range"] and r["class_speculation_slots"], r
         assert r["class_search_replays_reference"] and r["class_search_batched"], r
         assert r["class_replicated_equals_sharded"], r
+        assert r["unseeded_samples_equal"] and r["unseeded_seed"] == res[0]["unseeded_seed"], (r["unseeded_seed"], res[0]["unseeded_seed"])
     # the compact document built from sharded batches equals the single-process one (built here, same scenario)
     from monte_carlo_retirement_amd import Config
     from monte_carlo_retirement_amd import results as R
