@@ -854,6 +854,7 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
     for (int i = 0; i < n_cand; ++i) { io.snap_months[i] = working_months[order[i]]; io.cand_out[i] = order[i]; }
     const size_t snap_bytes = (size_t)n_cand * kSnapFields * (size_t)io.snap_stride * sizeof(double);
     const size_t blocks_bytes = (size_t)n_cand * sizeof(DevParams);
+    if (snap_bytes > ((size_t)4 << 30)) return MCR_ERR_UNSUPPORTED;   // huge probes are throughput-bound anyway: plain route
     void* mem = nullptr;
     if (hipMallocAsync(&mem, snap_bytes + blocks_bytes, stream) != hipSuccess) { (void)hipGetLastError(); return MCR_ERR_UNSUPPORTED; }
     io.snap = (double*)mem;
