@@ -73,6 +73,7 @@ constexpr double kRqCoarseSigmas = 7.0;    // its brackets leave room for the se
 constexpr int kRqMaxSubBins = 1024;        // sub-histogram bins per interval (stride of the global histograms)
 constexpr int kRqCoarseSubBits = 10;       // sample pass: 1024 bins per coarse interval
 constexpr int kRqWaves = 16;               // waves of the per-row kernels (1024 threads)
+constexpr int kRqWaveStage = 128;          // candidates a wave of the slab pass stages in LDS between two appends
 constexpr unsigned int kRqListCap = 12288; // keys of all wanted cells of one row (LDS of rq_select_kernel: 96 KB)
 // Scratch layout: RqRow[n_rows] | hist u32[n_rows][kRqMaxT][256] | aux u32[n_rows][2] | cand u64[n_rows][cap].
 // hist|aux is ONE dense block of 32-bit counters: a multi-GPU caller sums it across ranks after every
@@ -581,27 +582,30 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
 // 8 B/element read, a few % written.
 template <int P, bool COMPACT>
 __global__ __launch_bounds__(kRqBlock) void rq_count_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
-                                                           RqBracket* br, unsigned int* hist, int sub_bits, double* cand,
+                                                           RqBracket* br, unsigned int* hist, int sub_bits, int max_q, double* cand,
                                                            unsigned int cand_cap) {
-    constexpr int kWaveStage = 256;                      // candidates a wave collects in LDS before it appends them
-    __shared__ double stage[COMPACT ? (kRqBlock / 64) * kWaveStage : 1];
+    constexpr int kWaveStage = kRqWaveStage;             // candidates a wave collects in LDS before it appends them
     __shared__ unsigned long long bound[P];
     __shared__ int shl[P / 2];
     __shared__ double xlo_s[P / 2], invw_s[P / 2];
-    __shared__ unsigned int poshist[P * kRqBlock];
     __shared__ unsigned int nan_n;
-    extern __shared__ __align__(16) unsigned int subhist[];   // [P/2][2^sub_bits]
+    // dynamic LDS, sized by the host for the call's quantile count (every KB counts: 6 workgroups per CU at 7 quantiles):
+    // stage f64 [4][kWaveStage] (COMPACT) | poshist u32 [2 n_q + 1][256] | subhist u32 [n_q][2^sub_bits]
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    double* stage = reinterpret_cast<double*>(dyn_lds);
+    unsigned int* poshist = reinterpret_cast<unsigned int*>(dyn_lds + (COMPACT ? (kRqBlock / 64) * kWaveStage * sizeof(double) : 0));
+    unsigned int* subhist = poshist + (size_t)(2 * max_q + 1) * kRqBlock;
     const int row = blockIdx.y;
     RqBracket& B = br[row];
     const int nb = B.n_intervals;
-    if (B.fallback || 2 * nb >= P) return;             // (the host picks P > 2 * n_q >= 2 * nb)
+    if (B.fallback || 2 * nb >= P || nb > max_q) return;   // (the host picks P > 2 * n_q >= 2 * nb)
     const int bins = 1 << sub_bits;
     if (threadIdx.x < P) {
         const int b = threadIdx.x >> 1;
         bound[threadIdx.x] = b < nb ? ((threadIdx.x & 1) ? B.hi[b] + 1ull : B.lo[b]) : ~0ull;   // hi <= key(+inf): no wrap
         if ((threadIdx.x & 1) == 0) { shl[b] = b < nb ? B.shift[b] : 0; xlo_s[b] = b < nb ? B.xlo[b] : 0.0; invw_s[b] = b < nb ? B.inv_w[b] : 0.0; }
     }
-    for (int k = threadIdx.x; k < P * kRqBlock; k += kRqBlock) poshist[k] = 0u;
+    for (int k = threadIdx.x; k < (2 * nb + 1) * kRqBlock; k += kRqBlock) poshist[k] = 0u;
     for (int k = threadIdx.x; k < nb * bins; k += kRqBlock) subhist[k] = 0u;
     if (threadIdx.x == 0) nan_n = 0u;
     unsigned int keep = 0u;                            // bit b: interval b is a real range (lo < hi): members are candidates
@@ -1379,22 +1383,27 @@ static void rq_opt_in_lds(int device) {
     (void)hipFuncSetAttribute((const void*)rq_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void*)rq_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void*)rq_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_count_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipGetLastError();
     lds_opt_in_device = device;
 }
 
 // One counting pass over the first `len` entries of every row.
 static void rq_count_pass(hipStream_t s, const double* rows, int64_t row_stride, int32_t n_rows, int64_t len, RqBracket* br,
-                          unsigned int* hist, int sub_bits, bool compact, bool small_p, double* bcand, unsigned int bcap) {
+                          unsigned int* hist, int sub_bits, bool compact, int n_q, double* bcand, unsigned int bcap) {
+    const bool small_p = 2 * n_q < 16;                        // bound table: the next power of two above 2 * (intervals <= quantiles)
     // slab pass: ~4096 workgroups in flight; sample pass: few per row — every workgroup flushes its sub-histograms
     // (up to 1024 bins per interval) with global atomics, and the sample is only 1/32 of the slab
     const int per_row = compact ? (4096 / n_rows > 0 ? 4096 / n_rows : 1) : (1024 / n_rows > 1 ? 1024 / n_rows : 2);
     const int bx = grid_for(len > 0 ? len : 1, kRqBlock * 16, per_row);
     const dim3 grid(bx, n_rows), block(kRqBlock);
-    const size_t lds = (size_t)(small_p ? 8 : 16) * ((size_t)1 << sub_bits) * sizeof(unsigned int);
-#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, bcand, bcap)
+    const int max_q = n_q;
+    const size_t lds = (compact ? (size_t)(kRqBlock / 64) * kRqWaveStage * sizeof(double) : 0) +
+                       (size_t)(2 * max_q + 1) * kRqBlock * sizeof(unsigned int) + (size_t)max_q * ((size_t)1 << sub_bits) * sizeof(unsigned int);
+#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap)
     if (small_p) { if (compact) MCR_COUNT(16, true); else MCR_COUNT(16, false); }
     else { if (compact) MCR_COUNT(32, true); else MCR_COUNT(32, false); }
 #undef MCR_COUNT
@@ -1561,10 +1570,9 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     if (m > n) m = n;
     m &= ~(int64_t)1;
     const int sub_bits2 = n <= ((int64_t)1 << 24) ? 8 : 10;   // cells of a few hundred keys either way
-    const bool small_p = 2 * n_q < 16;                        // bound table: the next power of two above 2 * (intervals <= quantiles)
     const unsigned int bcap = rq_bracket_cand_cap(n);
     auto count_pass = [&](int64_t len, RqBracket* br, unsigned int* hist, int sub_bits, bool compact) {
-        rq_count_pass(s, rows, row_stride, n_rows, len, br, hist, sub_bits, compact, small_p, L.bcand, bcap);
+        rq_count_pass(s, rows, row_stride, n_rows, len, br, hist, sub_bits, compact, n_q, L.bcand, bcap);
     };
     count_pass(m, L.br1, L.hist1, kRqCoarseSubBits, false);
     hipLaunchKernelGGL(rq_refine_kernel, dim3(n_rows), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), s, m, a, L.br1,
@@ -1638,7 +1646,6 @@ int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_
     };
     const int blocks = (n_rows + 255) / 256;
     const unsigned int bcap = rq_bracket_cand_cap(n_local);
-    const bool small_p = 2 * n_q < 16;
     const int sub_bits2 = n_total <= ((int64_t)1 << 24) ? 8 : 10;
     hipError_t e = hipSuccess;
     // (1) coarse brackets: rank 0's first sample decides for everybody
@@ -1653,7 +1660,7 @@ int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_
     int64_t m_local = (m_total + world - 1) / world;
     if (m_local > n_local) m_local = n_local;
     m_local &= ~(int64_t)1;
-    rq_count_pass(s, rows, row_stride, n_rows, m_local, L.br1, L.hist1, kRqCoarseSubBits, false, small_p, L.bcand, bcap);
+    rq_count_pass(s, rows, row_stride, n_rows, m_local, L.br1, L.hist1, kRqCoarseSubBits, false, n_q, L.bcand, bcap);
     hipLaunchKernelGGL(rq_pack_kernel, dim3(blocks), dim3(256), 0, s, L.br1, L.cnt, (int)n_rows, bcap);
     if ((rc = sum(L.cnt, L.cnt_words, MCR_DT_I64, "sample counts")) != MCR_OK) return rc;
     if ((rc = sum(L.hist1, L.hist_words, MCR_DT_I32, "sample sub-histograms")) != MCR_OK) return rc;
@@ -1661,7 +1668,7 @@ int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_
     hipLaunchKernelGGL(rq_refine_kernel, dim3(n_rows), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), s, (int64_t)0, a,
                        L.br1, L.hist1, L.br2, L.hist2, sub_bits2, L.gfill);
     // (4) the one pass over the local slab; this rank's own sub-histograms are kept aside (hist1 is free again)
-    rq_count_pass(s, rows, row_stride, n_rows, n_local, L.br2, L.hist2, sub_bits2, true, small_p, L.bcand, bcap);
+    rq_count_pass(s, rows, row_stride, n_rows, n_local, L.br2, L.hist2, sub_bits2, true, n_q, L.bcand, bcap);
     e = hipMemcpyAsync(L.hist1, L.hist2, L.hist_words * sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return hip_fail(e, "sharded quantiles");
     hipLaunchKernelGGL(rq_pack_kernel, dim3(blocks), dim3(256), 0, s, L.br2, L.cnt, (int)n_rows, bcap);
