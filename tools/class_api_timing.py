@@ -1,9 +1,9 @@
 import json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from monte_carlo_retirement_amd import Config
 from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
-cfg = Config(**dict(json.load(open("scenarios/jorge.json")), seed=12345, equity_inflation_correlation=0.3))
+cfg = Config(**dict(json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenarios/jorge.json"))), seed=12345, equity_inflation_correlation=0.3))
 sim = RetirementMonteCarloSimulator(cfg); sim.use_final_seeds()
 sim.run_monte_carlo_simulations(75, 100000)
 for n in (1_000_000, 10_000_000):

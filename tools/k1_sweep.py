@@ -1,6 +1,6 @@
 """K1 count-only timing over batch sizes (GPU box): median of 5 launches per size, config.json wm=233."""
 import json, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monte_carlo_retirement_amd import Config, params_from_config
 from monte_carlo_retirement_amd import engine as E

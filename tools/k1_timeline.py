@@ -2,7 +2,7 @@
 Needs the instrumented build:  python -c "from monte_carlo_retirement_amd.csrc import build; build.build(force=True, extra_flags=['-DMCR_K1_TIMELINE'])"
 (then rebuild without the flag).  Output kept under profiles/r02/k1_timeline_*.txt."""
 import json, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monte_carlo_retirement_amd import Config, params_from_config
 from monte_carlo_retirement_amd import engine as E, _native as N

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
 os.environ["MCR_RQ_BRACKET_MIN_N"] = "1"
 from monte_carlo_retirement_amd import aggregation as A

@@ -1,11 +1,11 @@
 """K3 timing on the configs[2] shape (jorge rho=0.3, wm=75): bands of the [136, n] slab, median of 5 event-timed calls."""
 import json, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monte_carlo_retirement_amd import Config, params_from_config
 from monte_carlo_retirement_amd import aggregation as A, engine as E
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-cfg = Config(**dict(json.load(open("scenarios/jorge.json")), equity_inflation_correlation=0.3, seed=12345))
+cfg = Config(**dict(json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenarios/jorge.json"))), equity_inflation_correlation=0.3, seed=12345))
 b = E.DeviceBatch(params_from_config(cfg), 75, n, want="full")
 b.launch(12345, 1, 0)
 ts = []

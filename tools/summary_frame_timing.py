@@ -1,10 +1,10 @@
 """Where the host time of run_monte_carlo_simulations goes at 10^7 paths (beyond the ~71 ms of kernels)."""
 import json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monte_carlo_retirement_amd import Config, params_from_config, engine as E, aggregation as A
 from monte_carlo_retirement_amd import simulation as S
-cfg = Config(**dict(json.load(open("scenarios/jorge.json")), seed=12345, equity_inflation_correlation=0.3))
+cfg = Config(**dict(json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenarios/jorge.json"))), seed=12345, equity_inflation_correlation=0.3))
 n = 10_000_000
 def T(label, fn, reps=3):
     ts = []

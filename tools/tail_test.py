@@ -1,5 +1,5 @@
 import json, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from monte_carlo_retirement_amd import Config, params_from_config
 from monte_carlo_retirement_amd import engine as E
