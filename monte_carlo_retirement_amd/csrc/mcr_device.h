@@ -78,8 +78,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        // hi ^ counter ^ key as ONE v_bitop3_b32 (truth table 0x96 = three-way xor; gfx950) once all three operands are
+        // per-lane values — in the first rounds parts are still wave-uniform and fold into scalar xors
+        const uint32_t n0 = r >= 2 ? __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96) : (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = r >= 1 ? __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96) : (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void shock_row_phase(ShockGen& G, uint64_t seed, uint
     }
     if (PHASE == 1 || PHASE == 2) { G.cw0 = x[2]; G.cw1 = x[3]; }
     z_eq = n0;
-    z_inf = rho * n0 + rho_c * n1;
+    z_inf = __builtin_fma(rho, n0, rho_c * n1);
     z_prem = n2;
 }
 
@@ -159,7 +161,7 @@ __device__ __forceinline__ void shock_row_seq(ShockGen& G, uint64_t seed, uint32
 
 // _monthly_gross_from_shock (:468-474) with a = mu_log/12 and b = sigma_log/sqrt(12) precomputed.
 __device__ __forceinline__ double monthly_gross(double a, double b, double z, const double* tab) {
-    return fexp(a + b * z, tab);
+    return fexp(__builtin_fma(b, z, a), tab);   // (one rounding instead of the reference's two: 1e-16 |x| on the argument)
 }
 
 // TWO consecutive months at once.  Rows 4t .. 4t+3 of a path use exactly Philox blocks 3t .. 3t+2 -> Box-Muller
@@ -196,7 +198,7 @@ __device__ __forceinline__ void growth_rows2(const DevParams& P, uint64_t seed, 
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const double z_eq = n[3 * r], z_prem = n[3 * r + 2];
-        const double z_inf = P.rho * n[3 * r] + P.rho_c * n[3 * r + 1];       // :461-464
+        const double z_inf = __builtin_fma(P.rho, n[3 * r], P.rho_c * n[3 * r + 1]);   // :461-464
         const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab);
         const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab);
         const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab);

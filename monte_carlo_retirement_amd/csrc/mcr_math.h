@@ -8,7 +8,7 @@
 //   fdiv / recip_nr   the IEEE division sequence without v_div_scale/v_div_fixup: bit-identical to
 //                     `a / b` whenever no exponent scaling is needed (balances live in 1e-6..1e15);
 //                     the Newton reciprocal is shared by quotients with the same divisor.
-//   fexp              exp(x), |x| < 700: 2^(k/512) table (LDS, 4 KB) + degree-4 polynomial, <= ~1.5 ulp.
+//   fexp              exp(x), |x| < 700: 2^(k/512) table (LDS, 4 KB) + degree-4 polynomial, <= ~1.5 ulp + 0.5 ulp per unit of |x|.
 //   neg2_log_u32      -2 ln((x+0.5) 2^-32) straight from the Philox integer: 128-entry table of
 //                     (1/c, -2 ln c) + degree-6 series, <= 1.5 ulp of the result (Box-Muller radius^2).
 //   fsqrt             sqrt(w) for normal positive w: v_rsq_f64 + Goldschmidt + 1 correction, <= 1 ulp.
@@ -56,14 +56,19 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
 template <bool FULL = true>
 __device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr<FULL>(b)); }
 
+constexpr double kExpStep = 0x1.62e42fefa39efp-10;   // ln 2 / 512, correctly rounded
+constexpr double kM2Ln2 = -0x1.62e42fefa39efp+0;     // -2 ln 2, correctly rounded
+
 __device__ __forceinline__ double fexp(double x, const double* tab) {
     // k = rint(x 512/ln2) by the shifter trick: the sum lands on the unit grid of [2^52, 2^53), so its low word IS k
     // (two's complement) and subtracting the shifter gives k as a double: no v_rndne / v_cvt_i32.
     const double shifted = __builtin_fma(x, kExpScale, 6755399441055744.0);   // 1.5 * 2^52
     const int k = (int)(uint32_t)(uint64_t)__double_as_longlong(shifted);
     const double kf = shifted - 6755399441055744.0;
-    double r = __builtin_fma(-kf, kExpStepHi, x);      // exact: |kf| < 2^20 and the step's low 21 bits are zero
-    r = __builtin_fma(-kf, kExpStepLo, r);
+    // one-constant reduction: the step's representation error (1.1e-16 relative) times |k| step ~ |x| adds 1.1e-16 |x| to
+    // r, i.e. half an ulp of the result per unit of |x| — monthly log-returns are |x| < 2 (a two-constant Cody-Waite
+    // reduction only pays for arguments this kernel never sees)
+    const double r = __builtin_fma(-kf, kExpStep, x);
     const double t = tab[kTabExp2 + (k & ((1 << kExp2Bits) - 1))];
     // e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24), |r| <= ln2/1024: the next term r^5/120 < 1.2e-18
     double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
@@ -79,32 +84,33 @@ __device__ __forceinline__ double fexp(double x, const double* tab) {
 }
 
 __device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab) {
-    const double d = __builtin_fma((double)x, 2.0, 1.0);  // 2x+1, exact, in [1, 2^33)
-    const uint64_t bits = (uint64_t)__double_as_longlong(d);
-    const uint32_t hi = (uint32_t)(bits >> 32);
+    const double d = __builtin_fma((double)x, 2.0, 1.0);  // 2x+1, exact, in [1, 2^33);  u = d 2^-33
+    const uint32_t hi = (uint32_t)((uint64_t)__double_as_longlong(d) >> 32);
     const int i = (int)((hi >> 13) & 127u);               // top 7 fraction bits
-    const double m = __longlong_as_double((long long)((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
-    const double inv_c = tab[kTabLog + 2 * i], w_i = tab[kTabLog + 2 * i + 1];
-    const double r = __builtin_fma(m, inv_c, -1.0);       // |r| <= 2^-8
-    // -2 ln(1+r) = -2r + r^2 (1 - 2r/3 + r^2/2 - 2r^3/5 + r^4/3)
-    double p = __builtin_fma(r, 1.0 / 3.0, -0.4);
-    p = __builtin_fma(r, p, 0.5);
-    p = __builtin_fma(r, p, -2.0 / 3.0);
-    p = __builtin_fma(r, p, 1.0);
-    const double q = __builtin_fma(r * r, p, -2.0 * r);
-    const double e = (double)((int)(hi >> 20) - (1023 + 33));  // u = (2x+1) 2^-33
-    const double w = __builtin_fma(e, kM2Ln2Hi, w_i);     // e * hi is exact (21 trailing zero bits)
-    return w + __builtin_fma(e, kM2Ln2Lo, q);
+    const double m = __builtin_amdgcn_frexp_mant(d);      // d = m 2^ex, m in [1/2, 1): v_frexp_mant_f64 / v_frexp_exp_i32_f64
+    const int ex = __builtin_amdgcn_frexp_exp(d);
+    const double inv_c = tab[kTabLog + 2 * i], w_i = tab[kTabLog + 2 * i + 1];   // 1/c_i and -2 ln c_i, c_i in [1, 2)
+    // r = 2m / c_i - 1, |r| <= 2^-8; the code works with s = r/2 = m / c_i - 1/2 (no mantissa rebuilt in integer ops):
+    // -2 ln(1+r) = -2r + r^2 (1 - 2r/3 + r^2/2 - 2r^3/5 + r^4/3) = 4 (s^2 p(2s) - s); every coefficient below is a
+    // power-of-two multiple of the series', so the Horner values are the same bits as in terms of r
+    const double sh = __builtin_fma(m, inv_c, -0.5);
+    double p = __builtin_fma(sh, 16.0 / 3.0, -3.2);
+    p = __builtin_fma(sh, p, 2.0);
+    p = __builtin_fma(sh, p, -4.0 / 3.0);
+    p = __builtin_fma(sh, p, 1.0);
+    const double q4 = __builtin_fma(sh * sh, p, -sh);      // (-2 ln(1+r)) / 4
+    const double e = (double)(ex - 34);                   // u = (2m) 2^(ex - 34)
+    // e (-2 ln 2) + w_i in one FMA: the constant's representation error is 8e-17 of the product, and the product is the
+    // bulk of the result whenever |e| > 1 (for e = -1 it is 1.1e-16 absolute)
+    return __builtin_fma(4.0, q4, __builtin_fma(e, kM2Ln2, w_i));
 }
 
 __device__ __forceinline__ double fsqrt(double w) {  // w normal, > 0
+    // v_rsq_f64 seed + one coupled Goldschmidt step: the seed's relative error e becomes 1.5 e^2
     const double y = __builtin_amdgcn_rsq(w);
-    double g = w * y, h = 0.5 * y;
+    const double g = w * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, w);   // the Goldschmidt step leaves g good to ~2^-50; this correction squares that
-    return __builtin_fma(d, h, g);
+    return __builtin_fma(g, r, g);
 }
 
 template <bool WANT_SIN>
@@ -117,8 +123,9 @@ __device__ __forceinline__ void sincos_u32(uint32_t x, const double* tab, double
     double cp = __builtin_fma(d2, -1.0 / 720.0, 1.0 / 24.0);
     cp = __builtin_fma(d2, cp, -0.5);
     const double cd = d2 * cp;                                                               // cos(dl) - 1
-    c = C + __builtin_fma(C, cd, -(S * sd));
-    if (WANT_SIN) s = S + __builtin_fma(S, cd, C * sd);
+    const double cosd = 1.0 + cd;                                                            // (shared by both outputs)
+    c = __builtin_fma(C, cosd, -(S * sd));
+    if (WANT_SIN) s = __builtin_fma(S, cosd, C * sd);
 }
 
 }  // namespace mcr

@@ -57,7 +57,7 @@ def test_helpers_bit_exact_vs_reference():
             assert bool(row[4]) == r["out"][4]
     got = E.eval_helper_host(N.MCR_HELPER_MONTHLY_GROSS, None, [[r["mu_log"], r["sigma_log"], r["z"]] for r in g["monthly_gross"]])
     exp = np.array([r["gross"] for r in g["monthly_gross"]])
-    np.testing.assert_allclose(got[:, 0], exp, rtol=4e-16)  # device exp vs glibc exp: <= 1-2 ulp
+    np.testing.assert_allclose(got[:, 0], exp, rtol=6e-16)  # device exp (fused argument) vs glibc exp: <= 2 ulp + the argument's 1/2 ulp
 
 
 def test_reference_helper_unit_pins():
@@ -77,12 +77,13 @@ def test_reference_helper_unit_pins():
 
 
 def test_shock_rows_match_oracle(oracle):
-    """Philox integers are exact; Box-Muller goes through log/sqrt/sincospi: abs 1e-14."""
+    """Philox integers are exact; Box-Muller goes through log/sqrt/sincospi: 1.5e-14 relative (the radius: one-step
+    sqrt, tests/test_gpu_math.py) + 3e-15 absolute (angle and logarithm)."""
     for seed, stream, pb, rho in [(12345, 1, 0, 0.3), (2**40 + 17, 0, 2**33 + 5, -1.0), (7, 1, 2**32 - 2, 1.0)]:
         got = E.draw_shocks_host(seed, stream, pb, 5, 700, rho)
         for i in range(5):
             exp = oracle.draw_shocks(seed, stream, pb + i, 700, rho)
-            np.testing.assert_allclose(got[i], exp, rtol=0, atol=1e-14)
+            np.testing.assert_allclose(got[i], exp, rtol=1.5e-14, atol=3e-15)
     a = E.draw_shocks_host(5, 1, 4, 1, 100, 1.0)[0]
     assert np.array_equal(a[:, 1], a[:, 0])  # rho = +1 preserved exactly (reference test :185-195)
     b = E.draw_shocks_host(5, 1, 4, 1, 100, -1.0)[0]
