@@ -250,14 +250,31 @@ def main():
     batch = E.DeviceBatch(params, WORKING_MONTHS, n, want="count", device=device)
     # The exchange step works on a COPY of the rank's running totals: all-reducing the accumulation vector in place
     # would feed every step's global sum back into the next step's local counters.
-    exch = torch.zeros(batch.reduce_vec.shape, dtype=batch.reduce_vec.dtype, device=comm_dev)
+    # Two copies, used alternately, and the all-reduce is asynchronous: step k's exchange runs on the communication
+    # stream while step k+1 computes (nothing on the launch stream waits for it until its buffer comes up again).
+    exch2 = [torch.zeros(batch.reduce_vec.shape, dtype=batch.reduce_vec.dtype, device=comm_dev) for _ in range(2)]
+    pending = [None, None]
+    exch = exch2[0]
+
+    def exchange(i):
+        # the path's single exchange step: counters + year bins, summed over the ranks
+        j = i & 1
+        if pending[j] is not None:
+            pending[j].wait()
+        exch2[j].copy_(batch.reduce_vec, non_blocking=True)
+        pending[j] = dist.all_reduce(exch2[j], async_op=True)
+
+    def drain():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
 
     def step(i):
         # global path index: step-major, then rank (every path of the job is distinct)
         batch.launch(12345, 1, (i * world + rank) * n)
         if world > 1:
-            exch.copy_(batch.reduce_vec, non_blocking=True)
-            dist.all_reduce(exch)  # the path's single exchange step: counters + year bins, summed
+            exchange(i)
 
     def fence():
         if world > 1:
@@ -266,6 +283,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     batch.zero_counters()
@@ -276,8 +294,8 @@ def main():
         batch.launch(12345, 1, ((args.warmup + i) * world + rank) * n)
         ev[i][1].record()
         if world > 1:
-            exch.copy_(batch.reduce_vec, non_blocking=True)
-            dist.all_reduce(exch)
+            exchange(i)
+    drain()
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
@@ -286,7 +304,7 @@ def main():
     dt = float(tmax.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # HIP events on the launch stream
     # local running totals of the timed steps; with N ranks the last exchange holds the job's totals
-    counters = (exch if world > 1 else batch.reduce_vec)[:2].cpu().tolist()
+    counters = (exch2[(args.steps - 1) & 1] if world > 1 else batch.reduce_vec)[:2].cpu().tolist()
 
     s60 = None
     if not args.no_s60:
@@ -323,7 +341,7 @@ def main():
                 "paths_per_gpu_per_step": n,
                 "rng": "Philox4x32-10 + Box-Muller, counter=(path,month,stream), key=seed",
                 "parallelism": f"path-range sharding x{world}" + (
-                    f" + 1 all-reduce(sum) of the {exch.numel()}-word counter/bin vector per step ({args.backend})" if world > 1 else ""),
+                    f" + 1 all-reduce(sum) of the {exch.numel()}-word counter/bin vector per step ({args.backend}), overlapped with the next step's compute" if world > 1 else ""),
             },
             "roofline": {
                 "kernel": "mcr::path_kernel<0, 0, true, false>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
