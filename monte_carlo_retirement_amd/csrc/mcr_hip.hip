@@ -77,20 +77,26 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P_arg, 
     // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
     // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
     const DevParams& P = PHASE == 2 ? cand_params[blockIdx.y] : P_arg;
+    // LDS.  STATIC: the math tables (mcr_math.h) and, for the Philox stream, the [6][kBlock] stage of two months' gross
+    // factors — static because the compiler then knows their addresses (offset 0 ...) and a table lookup is index << 3 +
+    // ds_read with an immediate offset; against the dynamic region every address is `base + ...` with a base it only learns
+    // to be 0 after instruction selection: v_lshl_add_u32 x, 3, 0 (a 3-operand op, 4.6 cycles instead of 2.7) or a literal
+    // v_add_u32 0.  DYNAMIC: the NumPy ziggurat tables, [n_lock_slots][kBlock] doubles (frozen nominal stream amounts),
+    // the block counters.
+    constexpr bool kStaged = RNG == (int)MCR_RNG_PHILOX && !INJ;
+    __shared__ __align__(16) double tab_s[kTabDoubles];
+    __shared__ __align__(16) double stage_s[kStaged ? kStageDoubles : 1];
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // LDS: math tables (mcr_math.h), then the NumPy ziggurat tables OR (Philox stream) the [6][kBlock] stage of two
-    // months' gross factors, [n_lock_slots][kBlock] doubles (frozen nominal stream amounts), then block counters
 #ifdef MCR_K1_TIMELINE   // diagnostic build only (tools/k1_timeline.py): per-wave start / end stamps and placement
     const unsigned long long tl_t0 = wall_clock64();
 #endif
-    double* tab = reinterpret_cast<double*>(smem_raw);
+    double* tab = tab_s;
     load_math_tables(tab, threadIdx.x, kBlock);
     ZigTables zig{nullptr, nullptr, nullptr};
-    if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw + kMathTabBytes, threadIdx.x, kBlock);
+    if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw, threadIdx.x, kBlock);
     // Philox stream: the gross factors of two months at a time, staged per lane (growth_rows2)
-    constexpr bool kStaged = RNG == (int)MCR_RNG_PHILOX && !INJ;
-    double* stage = reinterpret_cast<double*>(smem_raw + kMathTabBytes + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0)) + threadIdx.x;
-    double* lock_lds = stage - threadIdx.x + (kStaged ? kStageDoubles : 0);
+    double* stage = stage_s + (kStaged ? threadIdx.x : 0);
+    double* lock_lds = reinterpret_cast<double*>(smem_raw + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0));
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
     // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram
     const int ry = P.retirement_years;
@@ -673,8 +679,10 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     return MCR_OK;
 }
 
+constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)kStageDoubles * sizeof(double);   // (upper bound over the variants)
 static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng) {
-    return (size_t)kMathTabBytes + (numpy_rng ? (size_t)kZigLdsBytes : (size_t)kStageDoubles * sizeof(double)) +
+    // the dynamic part only: the math tables and the stage of growth factors are static LDS of the kernel
+    return (numpy_rng ? (size_t)kZigLdsBytes : (size_t)0) +
            (size_t)d.n_lock_slots * kBlock * sizeof(double) +
            (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1)) * sizeof(unsigned int);
 }
@@ -726,7 +734,7 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     }
     const bool np_rng = rng->kind == MCR_RNG_NUMPY;
     const size_t lds = path_kernel_lds_bytes(d, np_rng);
-    if (lds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
+    if (lds + kPathKernelStaticLds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
     // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
@@ -843,7 +851,7 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
     }
     const DevParams& top = blocks[(size_t)n_cand - 1];
     const size_t lds = path_kernel_lds_bytes(top, false);
-    if (lds > 64 * 1024) return MCR_ERR_UNSUPPORTED;
+    if (lds + kPathKernelStaticLds > 64 * 1024) return MCR_ERR_UNSUPPORTED;
     KernelIO io;
     std::memset(&io, 0, sizeof(io));
     fill_io_rng(io, rng, nullptr);

@@ -67,6 +67,13 @@ KERNEL(and_b32, uint32_t, seed + threadIdx.x + c, ASM2("v_and_b32"))
 KERNEL(mov_b64, double, seed + threadIdx.x + c, asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(seed)))
 KERNEL(addc_only, uint32_t, seed + threadIdx.x + c, asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(x) : : "vcc"))
 
+KERNEL(bfi_b32, uint32_t, seed + threadIdx.x + c, ASM3("v_bfi_b32"))
+KERNEL(bitop3_b32, uint32_t, seed + threadIdx.x + c, asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0x96" : "+v"(x) : "v"(seed)))
+KERNEL(bitop3_sgpr, uint32_t, seed + threadIdx.x + c, asm volatile("v_bitop3_b32 %0, %0, %1, s20 bitop3:0x96" : "+v"(x) : "v"(seed)))
+KERNEL(lshl_add_u32, uint32_t, seed + threadIdx.x + c, asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(seed)))
+KERNEL(add3_u32, uint32_t, seed + threadIdx.x + c, ASM3("v_add3_u32"))
+KERNEL(frexp_exp_f64, double, seed + threadIdx.x + c, { uint32_t e; asm volatile("v_frexp_exp_i32_f64 %0, %1" : "=v"(e) : "v"(x)); })
+
 template <typename T>
 static void run(const char* name, void (*k)(T*, T), T seed) {
     T* d;
@@ -104,5 +111,7 @@ int main() {
     RUN(cmp_lt_u64, uint64_t, 3); RUN(cmp_lt_u32, uint32_t, 3); RUN(cmp_eq_u64, uint64_t, 3);
     RUN(cmp_addc_u64, uint64_t, 3); RUN(cmp_addc_u32, uint32_t, 3); RUN(addc_only, uint32_t, 3);
     RUN(cndmask_sgpr, uint32_t, 3); RUN(cndmask_vcc_e32, uint32_t, 3); RUN(cndmask_vcc_e64, uint32_t, 3); RUN(addc_vcc_e32, uint32_t, 3); RUN(cndmask_dpp_free, uint32_t, 3); RUN(rcp_f32, float, 1.5f); RUN(cvt_f32_f64, double, 1.5); RUN(cvt_f64_f32, double, 1.5); RUN(min_f64, double, 1.5); RUN(and_b32, uint32_t, 3); RUN(mov_b64, double, 1.5);
+    RUN(bfi_b32, uint32_t, 3); RUN(bitop3_b32, uint32_t, 3); RUN(bitop3_sgpr, uint32_t, 3); RUN(lshl_add_u32, uint32_t, 3); RUN(add3_u32, uint32_t, 3);
+    RUN(frexp_exp_f64, double, 1.5);
     return 0;
 }
