@@ -67,7 +67,9 @@ def main(src: str, dst: str) -> None:
         "K1_count_trans_f64_per_path_month": m(k0, "SQ_INSTS_VALU_TRANS_F64") / wave_months,
         "K1_count_lds_insts_per_path_month": m(k0, "SQ_INSTS_LDS") / wave_months,
         "K1_count_hbm_bytes_per_launch": (2 * m(k0, "FETCH_SIZE") + m(k0, "WRITE_SIZE")) * 1024,
-        "shader_clock_GHz_K1_count": m(k0, "GRBM_GUI_ACTIVE") / 8 / (k1_ms * 1e-3) / 1e9,
+        # (cycles counted in the PMC pass over the duration measured in the TRACE pass: the shader clock only if both
+        #  passes ran the kernel at the same speed — they are separate runs)
+        "GRBM_GUI_ACTIVE_per_XCD_over_trace_duration_GHz": m(k0, "GRBM_GUI_ACTIVE") / 8 / (k1_ms * 1e-3) / 1e9,
         "K1_full_WRITE_SIZE_bytes_per_launch": m(k2, "WRITE_SIZE") * 1024,
         "K1_full_algorithmic_write_bytes": alg_full,
         "K1_full_write_efficiency_algorithmic_over_measured": alg_full / (m(k2, "WRITE_SIZE") * 1024),
