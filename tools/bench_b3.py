@@ -38,6 +38,7 @@ def main():
     T, ry = b.sizes.trajectory_len, b.sizes.retirement_years
 
     def timed(fn):
+        fn()                                  # first call: scratch allocation (15 GB at 1e8 paths)
         ts = []
         for _ in range(args.reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
