@@ -67,6 +67,15 @@ KERNEL(and_b32, uint32_t, seed + threadIdx.x + c, ASM2("v_and_b32"))
 KERNEL(mov_b64, double, seed + threadIdx.x + c, asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(seed)))
 KERNEL(addc_only, uint32_t, seed + threadIdx.x + c, asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, s[20:21]" : "+v"(x) : : "vcc"))
 
+// mixes: is the transcendental pipe separate from the fp64 pipe (do the costs add or overlap)?  Every chain does one
+// independent FMA per iteration; every 4th chain also issues one transcendental (or four xors) with a throw-away result.
+// The printed figure is per FMA: compare with fma_f64 alone and with fma + the other op's cost / 4.
+#define FMA1 asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(x) : "v"(seed))
+KERNEL(mix_rcp64_per_4fma, double, seed + threadIdx.x + c, { if ((c & 3) == 0) { double t; asm volatile("v_rcp_f64 %0, %1" : "=v"(t) : "v"(seed)); } FMA1; })
+KERNEL(mix_rcp32_per_4fma, double, seed + threadIdx.x + c, { if ((c & 3) == 0) { float t; asm volatile("v_rcp_f32 %0, %1" : "=v"(t) : "v"((float)seed)); } FMA1; })
+KERNEL(mix_4xor_per_4fma, double, seed + threadIdx.x + c, { uint32_t t; asm volatile("v_xor_b32 %0, %1, %1" : "=v"(t) : "v"((uint32_t)c)); FMA1; })
+KERNEL(mix_mad64_per_fma, double, seed + threadIdx.x + c, { uint64_t t; asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, 0" : "=v"(t) : "v"((uint32_t)c) : "vcc"); FMA1; })
+KERNEL(exp_f32, float, seed + threadIdx.x + c, ASM1("v_exp_f32"))
 KERNEL(bfi_b32, uint32_t, seed + threadIdx.x + c, ASM3("v_bfi_b32"))
 KERNEL(bitop3_b32, uint32_t, seed + threadIdx.x + c, asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0x96" : "+v"(x) : "v"(seed)))
 KERNEL(bitop3_sgpr, uint32_t, seed + threadIdx.x + c, asm volatile("v_bitop3_b32 %0, %0, %1, s20 bitop3:0x96" : "+v"(x) : "v"(seed)))
@@ -112,6 +121,8 @@ int main() {
     RUN(cmp_addc_u64, uint64_t, 3); RUN(cmp_addc_u32, uint32_t, 3); RUN(addc_only, uint32_t, 3);
     RUN(cndmask_sgpr, uint32_t, 3); RUN(cndmask_vcc_e32, uint32_t, 3); RUN(cndmask_vcc_e64, uint32_t, 3); RUN(addc_vcc_e32, uint32_t, 3); RUN(cndmask_dpp_free, uint32_t, 3); RUN(rcp_f32, float, 1.5f); RUN(cvt_f32_f64, double, 1.5); RUN(cvt_f64_f32, double, 1.5); RUN(min_f64, double, 1.5); RUN(and_b32, uint32_t, 3); RUN(mov_b64, double, 1.5);
     RUN(bfi_b32, uint32_t, 3); RUN(bitop3_b32, uint32_t, 3); RUN(bitop3_sgpr, uint32_t, 3); RUN(lshl_add_u32, uint32_t, 3); RUN(add3_u32, uint32_t, 3);
-    RUN(frexp_exp_f64, double, 1.5);
+    RUN(frexp_exp_f64, double, 1.5); RUN(exp_f32, float, 1.5f);
+    RUN(mix_rcp64_per_4fma, double, 1.0000001); RUN(mix_rcp32_per_4fma, double, 1.0000001); RUN(mix_4xor_per_4fma, double, 1.0000001);
+    RUN(mix_mad64_per_fma, double, 1.0000001);
     return 0;
 }
