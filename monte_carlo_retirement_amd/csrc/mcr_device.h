@@ -99,10 +99,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // a pure function of (seed, stream, path, k): common random numbers across working-month candidates
 // and across any sharding.  Rows are consumed in order, so a lane carries the half-used pair / block:
 // 4 rows cost 3 Philox blocks and 6 (log, sqrt, sincos) pairs instead of 4 and 8.
-__device__ __forceinline__ void bm_pair(uint32_t xr, uint32_t xa, const double* tab, double& zc, double& zs) {
-    const double r = fsqrt(neg2_log_u32(xr, tab));  // radius and angle straight from the Philox integers
+__device__ __forceinline__ void bm_pair(uint32_t xr, uint32_t xa, const double* tab, const MathRegs& R, double& zc, double& zs) {
+    const double r = fsqrt(neg2_log_u32(xr, tab, R));  // radius and angle straight from the Philox integers
     double s, c;
-    sincos_u32<true>(xa, tab, s, c);
+    sincos_u32<true>(xa, tab, R, s, c);
     zc = r * c;
     zs = r * s;
 }
@@ -130,12 +130,12 @@ __device__ __forceinline__ void shock_row_phase(ShockGen& G, uint64_t seed, uint
                       (uint32_t)(seed >> 32), x);
     const uint32_t ar = PHASE < 2 ? x[0] : G.cw0, aa = PHASE < 2 ? x[1] : G.cw1;
     double ac, as;
-    bm_pair(ar, aa, tab, ac, as);
+    bm_pair(ar, aa, tab, MathRegs::literals(), ac, as);
     double n0, n1, n2;
     if ((PHASE & 1) == 0) {
         const uint32_t br = PHASE == 0 ? x[2] : x[0], ba = PHASE == 0 ? x[3] : x[1];
         double bc, bs;
-        bm_pair(br, ba, tab, bc, bs);
+        bm_pair(br, ba, tab, MathRegs::literals(), bc, bs);
         n0 = ac; n1 = as; n2 = bc;
         G.carry_z = bs;
     } else {
@@ -160,8 +160,8 @@ __device__ __forceinline__ void shock_row_seq(ShockGen& G, uint64_t seed, uint32
 }
 
 // _monthly_gross_from_shock (:468-474) with a = mu_log/12 and b = sigma_log/sqrt(12) precomputed.
-__device__ __forceinline__ double monthly_gross(double a, double b, double z, const double* tab) {
-    return fexp(__builtin_fma(b, z, a), tab);   // (one rounding instead of the reference's two: 1e-16 |x| on the argument)
+__device__ __forceinline__ double monthly_gross(double a, double b, double z, const double* tab, const MathRegs& R = MathRegs::literals()) {
+    return fexp(__builtin_fma(b, z, a), tab, R);   // (one rounding instead of the reference's two: 1e-16 |x| on the argument)
 }
 
 // TWO consecutive months at once.  Rows 4t .. 4t+3 of a path use exactly Philox blocks 3t .. 3t+2 -> Box-Muller
@@ -178,30 +178,32 @@ __device__ __forceinline__ double monthly_gross(double a, double b, double z, co
 // the other waves).  Every value is produced by the same expressions as shock_row_seq + monthly_gross.
 struct PairCarry { uint32_t w2, w3; };
 template <int HALF>
-__device__ __forceinline__ void growth_rows2(const DevParams& P, uint64_t seed, uint32_t stream_id, uint64_t path,
+__device__ __forceinline__ void growth_rows2(const DevParams& P, const MathRegs& M, uint64_t seed, uint32_t stream_id, uint64_t path,
                                              uint32_t t, const double* tab, double* stage, PairCarry& C) {
     double n[6];
     uint32_t x[4];
     if (HALF == 0) {
         philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        bm_pair(x[0], x[1], tab, n[0], n[1]);
-        bm_pair(x[2], x[3], tab, n[2], n[3]);
+        bm_pair(x[0], x[1], tab, M, n[0], n[1]);
+        bm_pair(x[2], x[3], tab, M, n[2], n[3]);
         philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t + 1u, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        bm_pair(x[0], x[1], tab, n[4], n[5]);
+        bm_pair(x[0], x[1], tab, M, n[4], n[5]);
         C.w2 = x[2]; C.w3 = x[3];
     } else {
-        bm_pair(C.w2, C.w3, tab, n[0], n[1]);
+        bm_pair(C.w2, C.w3, tab, M, n[0], n[1]);
         philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t + 2u, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        bm_pair(x[0], x[1], tab, n[2], n[3]);
-        bm_pair(x[2], x[3], tab, n[4], n[5]);
+        bm_pair(x[0], x[1], tab, M, n[2], n[3]);
+        bm_pair(x[2], x[3], tab, M, n[4], n[5]);
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const double z_eq = n[3 * r], z_prem = n[3 * r + 2];
         const double z_inf = __builtin_fma(P.rho, n[3 * r], P.rho_c * n[3 * r + 1]);   // :461-464
-        const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab);
-        const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab);
-        const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab);
+        // (x = b z + a with a AND b in SGPRs costs two v_mov_b32 per evaluation — see MathRegs — but pinning the three a's in
+        //  VGPRs as well measured 9 % SLOWER, 7.06 -> 7.72 ms per 1e6 paths, for reasons the ISA does not show; they stay scalar)
+        const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab, M);
+        const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab, M);
+        const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab, M);
         stage[(3 * r + 0) * kBlock] = g1;
         stage[(3 * r + 1) * kBlock] = ginf;
         stage[(3 * r + 2) * kBlock] = ginf * gprem;                             // :532

@@ -71,8 +71,11 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // accumulation months for every probed candidate although, under common random numbers, they do not depend on it,
 // :513-579): PHASE 1 runs the accumulation once to the largest candidate and stores the state at the end of every
 // candidate month; PHASE 2 (grid.y = candidate) resumes each candidate's decumulation from its snapshot.
+#ifndef MCR_K1_WAVES_ATTR
+#define MCR_K1_WAVES_ATTR
+#endif
 template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0>
-__global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P_arg, const KernelIO io,
+__global__ __launch_bounds__(kBlock, 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
     // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P_arg, 
     // Top of every month (wave-uniform, outside any divergent region): rows are visited in order 0, 1, 2, ... across
     // both phases, so each pair of rows is generated exactly when its first row comes up.
     PairCarry carry{0u, 0u};
+    const MathRegs GR = kStaged ? MathRegs::pinned() : MathRegs::literals();
     // Wave priority falls as the path advances (s_setprio takes an immediate: four levels).  The SIMD arbitrates VALU
     // issue by priority, then age; left alone, the oldest wave of a SIMD runs far ahead and the youngest is left to
     // finish ALONE at the end of the launch, at a fraction of the SIMD's issue rate (measured with per-wave
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(kBlock, 4) void path_kernel(const DevParams P_arg, 
         else if (row == prio_t2) __builtin_amdgcn_s_setprio(1);
         else if (row == prio_t3) __builtin_amdgcn_s_setprio(0);
         if (kStaged && (row & 1) == 0) {
-            if ((row & 2) == 0) growth_rows2<0>(P, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
-            else growth_rows2<1>(P, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+            if ((row & 2) == 0) growth_rows2<0>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+            else growth_rows2<1>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
         }
     };
     // gross factors of month `row` (:522-532)
@@ -441,14 +445,14 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
             out[i] = monthly_gross(x[0] / (double)kMPY, x[1] / sqrt((double)kMPY), x[2], tab);  // :473
             break;
         }
-        case MCR_HELPER_MATH_EXP: out[i] = fexp(in[i], tab); break;
+        case MCR_HELPER_MATH_EXP: out[i] = fexp(in[i], tab, MathRegs::literals()); break;
         case MCR_HELPER_MATH_DIV: out[i] = fdiv(in[2 * i], in[2 * i + 1]); break;
         case MCR_HELPER_MATH_DIV_PATH: out[i] = fdiv<false>(in[2 * i], in[2 * i + 1]); break;
         case MCR_HELPER_MATH_SQRT: out[i] = fsqrt(in[i]); break;
-        case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab); break;
+        case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab, MathRegs::literals()); break;
         case MCR_HELPER_MATH_SINCOS: {
             double sn, cs;
-            sincos_u32<true>((uint32_t)in[i], tab, sn, cs);
+            sincos_u32<true>((uint32_t)in[i], tab, MathRegs::literals(), sn, cs);
             out[2 * i] = sn; out[2 * i + 1] = cs;
             break;
         }

@@ -56,10 +56,24 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
 template <bool FULL = true>
 __device__ __forceinline__ double fdiv(double a, double b) { return div_by(a, b, recip_nr<FULL>(b)); }
 
+// The addends of the two-constant FMAs below (p = r c1 + c0).  A VOP3 instruction reads at most ONE scalar operand on
+// gfx9, so with both constants in SGPRs the compiler copies one into a VGPR pair in front of every such FMA (a
+// v_mov_b64, or two v_mov_b32, per evaluation).  The path kernel keeps these few in VGPRs for the whole launch
+// (pinned(): an empty asm the register allocator cannot see through); everyone else passes literals().
+struct MathRegs {
+    double exp_c6;     // 1/6     (fexp)
+    double log_c0;     // -3.2    (neg2_log_u32)
+    double sin_c6;     // -1/6    (sincos_u32)
+    double cos_c24;    // 1/24
+    double ang_bias;   // kAngleBias
+    static __device__ __forceinline__ MathRegs literals();
+    static __device__ __forceinline__ MathRegs pinned();
+};
+
 constexpr double kExpStep = 0x1.62e42fefa39efp-10;   // ln 2 / 512, correctly rounded
 constexpr double kM2Ln2 = -0x1.62e42fefa39efp+0;     // -2 ln 2, correctly rounded
 
-__device__ __forceinline__ double fexp(double x, const double* tab) {
+__device__ __forceinline__ double fexp(double x, const double* tab, const MathRegs& R) {
     // k = rint(x 512/ln2) by the shifter trick: the sum lands on the unit grid of [2^52, 2^53), so its low word IS k
     // (two's complement) and subtracting the shifter gives k as a double: no v_rndne / v_cvt_i32.
     const double shifted = __builtin_fma(x, kExpScale, 6755399441055744.0);   // 1.5 * 2^52
@@ -71,7 +85,7 @@ __device__ __forceinline__ double fexp(double x, const double* tab) {
     const double r = __builtin_fma(-kf, kExpStep, x);
     const double t = tab[kTabExp2 + (k & ((1 << kExp2Bits) - 1))];
     // e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24), |r| <= ln2/1024: the next term r^5/120 < 1.2e-18
-    double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    double p = __builtin_fma(r, 1.0 / 24.0, R.exp_c6);
     p = __builtin_fma(r, p, 0.5);
     p = __builtin_fma(r * r, p, r);
     // t (1 + p) 2^(k >> 9): the scale goes straight into the exponent field of the high word (v_ashr + v_lshl_add_u32,
@@ -83,7 +97,7 @@ __device__ __forceinline__ double fexp(double x, const double* tab) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | (vb & 0xFFFFFFFFull)));
 }
 
-__device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab) {
+__device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab, const MathRegs& R) {
     const double d = __builtin_fma((double)x, 2.0, 1.0);  // 2x+1, exact, in [1, 2^33);  u = d 2^-33
     const uint32_t hi = (uint32_t)((uint64_t)__double_as_longlong(d) >> 32);
     const int i = (int)((hi >> 13) & 127u);               // top 7 fraction bits
@@ -94,7 +108,7 @@ __device__ __forceinline__ double neg2_log_u32(uint32_t x, const double* tab) {
     // -2 ln(1+r) = -2r + r^2 (1 - 2r/3 + r^2/2 - 2r^3/5 + r^4/3) = 4 (s^2 p(2s) - s); every coefficient below is a
     // power-of-two multiple of the series', so the Horner values are the same bits as in terms of r
     const double sh = __builtin_fma(m, inv_c, -0.5);
-    double p = __builtin_fma(sh, 16.0 / 3.0, -3.2);
+    double p = __builtin_fma(sh, 16.0 / 3.0, R.log_c0);
     p = __builtin_fma(sh, p, 2.0);
     p = __builtin_fma(sh, p, -4.0 / 3.0);
     p = __builtin_fma(sh, p, 1.0);
@@ -114,18 +128,25 @@ __device__ __forceinline__ double fsqrt(double w) {  // w normal, > 0
 }
 
 template <bool WANT_SIN>
-__device__ __forceinline__ void sincos_u32(uint32_t x, const double* tab, double& s, double& c) {
+__device__ __forceinline__ void sincos_u32(uint32_t x, const double* tab, const MathRegs& R, double& s, double& c) {
     const int k = (int)(x >> 24);
     const double S = tab[kTabSinCos + 2 * k], C = tab[kTabSinCos + 2 * k + 1];
-    const double dl = __builtin_fma((double)(x & 0x00FFFFFFu), kAngleScale, kAngleBias);  // |dl| <= pi/256
+    const double dl = __builtin_fma((double)(x & 0x00FFFFFFu), kAngleScale, R.ang_bias);  // |dl| <= pi/256
     const double d2 = dl * dl;
-    const double sd = __builtin_fma(dl * d2, __builtin_fma(d2, 1.0 / 120.0, -1.0 / 6.0), dl);  // sin(dl)
-    double cp = __builtin_fma(d2, -1.0 / 720.0, 1.0 / 24.0);
+    const double sd = __builtin_fma(dl * d2, __builtin_fma(d2, 1.0 / 120.0, R.sin_c6), dl);  // sin(dl)
+    double cp = __builtin_fma(d2, -1.0 / 720.0, R.cos_c24);
     cp = __builtin_fma(d2, cp, -0.5);
     const double cd = d2 * cp;                                                               // cos(dl) - 1
     const double cosd = 1.0 + cd;                                                            // (shared by both outputs)
     c = __builtin_fma(C, cosd, -(S * sd));
     if (WANT_SIN) s = __builtin_fma(S, cosd, C * sd);
+}
+
+__device__ __forceinline__ MathRegs MathRegs::literals() { return MathRegs{1.0 / 6.0, -3.2, -1.0 / 6.0, 1.0 / 24.0, kAngleBias}; }
+__device__ __forceinline__ MathRegs MathRegs::pinned() {
+    MathRegs R = literals();
+    asm volatile("" : "+v"(R.exp_c6), "+v"(R.log_c0), "+v"(R.sin_c6), "+v"(R.cos_c24), "+v"(R.ang_bias));
+    return R;
 }
 
 }  // namespace mcr
