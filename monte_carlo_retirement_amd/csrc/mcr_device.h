@@ -200,7 +200,8 @@ __device__ __forceinline__ void growth_rows2(const DevParams& P, const MathRegs&
         const double z_eq = n[3 * r], z_prem = n[3 * r + 2];
         const double z_inf = __builtin_fma(P.rho, n[3 * r], P.rho_c * n[3 * r + 1]);   // :461-464
         // (x = b z + a with a AND b in SGPRs costs two v_mov_b32 per evaluation — see MathRegs — but pinning the three a's in
-        //  VGPRs as well measured 9 % SLOWER, 7.06 -> 7.72 ms per 1e6 paths, for reasons the ISA does not show; they stay scalar)
+        //  VGPRs as well takes the kernel past 80 VGPRs: 5 resident waves per SIMD instead of 6, which at 1e6 paths leaves
+        //  a lone fourth round, 7.06 -> 7.72 ms; held under 80 it spills.  They stay scalar.  DESIGN.md 5)
         const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab, M);
         const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab, M);
         const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab, M);
