@@ -122,6 +122,30 @@ def aux_hbm_kernels(torch, n):
     }
 
 
+def accuracy_10k():
+    """The second half of BASELINE's metric: |p_gpu - p_ref| on the 10k-path config (config.json, wm=233).  p_ref and
+    the per-path Success flags are the REFERENCE's own output, recorded in tests/golden/metric_10k_config_json.*
+    (generate_golden.py ran the reference on the engine's Philox shocks): data files, no oracle involved."""
+    import numpy as np
+
+    from monte_carlo_retirement_amd import Config, params_from_config
+    from monte_carlo_retirement_amd import engine as E
+
+    gdir = os.path.join(REPO, "tests", "golden")
+    with open(os.path.join(gdir, "metric_10k_config_json.json")) as fh:
+        meta = json.load(fh)
+    z = np.load(os.path.join(gdir, "metric_10k_config_json.npz"))
+    n = int(meta["n_paths"])
+    stream = {"search": 0, "final": 1}[meta["stream"]]
+    res = E.run_batch_host(params_from_config(Config(**meta["cfg"])), meta["seed"], stream, 0, n, meta["working_months"],
+                           want_trajectories=False)
+    flags = np.unpackbits(z["success_bits"])[:n]
+    p_gpu, p_ref = float(res["counters"][0]) / n, meta["success_count"] / n
+    return {"config": "BASELINE configs[0]: config.json, working_months=233, %d paths" % n, "p_gpu": p_gpu, "p_reference": p_ref,
+            "abs_error": abs(p_gpu - p_ref), "flipped_success_flags": int((res["success"] != flags).sum()),
+            "source": "tests/golden/metric_10k_config_json.{json,npz} (the reference's own flags on identical shocks)"}
+
+
 def s60_block(torch, dist, world, n_total, reps=3):
     """North-star shape (BASELINE configs[3]): S60 = config.json with initial_balance=2e6,
     inv1 volatility 0.15, rho=0.3, wm=120 (720-month paths); success counts + 100-bin histogram of the
@@ -359,6 +383,10 @@ def main():
             "success_probability": counters[0] / max(1, counters[1]),
             "paths_counted": counters[1],
         }
+        try:
+            out["accuracy_10k"] = accuracy_10k()
+        except Exception as exc:  # never lose the headline line to an auxiliary block
+            out["accuracy_10k"] = {"error": f"{type(exc).__name__}: {exc}"}
         if s60 is not None:
             out["s60"] = s60
         if not args.no_aux and world == 1:

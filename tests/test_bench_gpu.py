@@ -50,3 +50,6 @@ def test_bench_single_gpu_line_has_the_contract_keys():
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 4
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert out["s60"]["paths_counted"] == 400000 and out["hbm_kernels"]["K3_row_quantiles"]["rows"] == 136
+    acc = out["accuracy_10k"]      # BASELINE's "success-prob abs error vs CPU ref, 10k-path config"
+    assert "error" not in acc, acc
+    assert acc["abs_error"] <= 1e-4 and acc["flipped_success_flags"] == 0
