@@ -111,3 +111,27 @@ def test_product_package_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "liboracle" not in text and "mcr_oracle" not in text, f
+
+
+def build_c_caller(tmp_path) -> str:
+    """Compile examples/c_caller.c (plain C99 against include/mcr.h, linked with the built library)."""
+    import subprocess
+
+    exe = os.path.join(str(tmp_path), "c_caller")
+    libdir = os.path.join(REPO, "monte_carlo_retirement_amd", "csrc")
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"),
+           os.path.join(REPO, "examples", "c_caller.c"), "-o", exe, "-L", libdir, "-lmcr_hip", f"-Wl,-rpath,{libdir}", "-lm"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_plain_c_caller_compiles_and_fails_loudly_without_a_gpu(lib, tmp_path):
+    """The boundary is a C ABI: the header is valid C99 (-pedantic -Werror), a C program links against the library
+    with nothing but libm, and without a HIP device it exits with an error instead of computing anything."""
+    import subprocess
+
+    exe = build_c_caller(tmp_path)
+    if lib.mcr_device_count() > 0:
+        pytest.skip("a GPU is present (the run itself is tests/test_gpu_edge_cases.py)")
+    r = subprocess.run([exe, "1000"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""

@@ -4,6 +4,7 @@ very long horizons, degenerate scenarios, ragged batch sizes, argument errors.""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -291,3 +292,23 @@ def test_very_large_batches_use_64bit_addressing(oracle):
         o = oracle.run_batch(p, 31337, 1, int(g), 1, wm)
         np.testing.assert_allclose(samples[j], o["trajectory"][:, 0], rtol=REL, atol=ABS)
         np.testing.assert_allclose(rsamples[j], o["real_trajectory"][:, 0], rtol=REL, atol=ABS)
+
+
+def test_plain_c_caller_equals_the_python_path(tmp_path):
+    """examples/c_caller.c — C99, no Python, no torch, MCR_DEVICE_ALL — on the config.json scenario: the same success
+    count as the Python binding for the same seed and path range."""
+    import json
+    import subprocess
+
+    from test_abi_cpu import build_c_caller
+
+    exe = build_c_caller(tmp_path)
+    n, wm, seed = 200_000, 233, 987654321
+    r = subprocess.run([exe, str(n), str(wm), str(seed)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    fields = dict(kv.split("=") for kv in r.stdout.split())
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenarios", "config.json")) as fh:
+        cfg = Config(**json.load(fh))
+    ref = E.run_batch_host(params_from_config(cfg), seed, 1, 0, n, wm, want_summary=False, want_trajectories=False)
+    assert int(fields["paths"]) == n == int(ref["counters"][1])
+    assert int(fields["success"]) == int(ref["counters"][0])
