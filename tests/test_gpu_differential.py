@@ -4,6 +4,8 @@ huge volatilities, negative means, up to 6 random income streams, random horizon
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
@@ -48,10 +50,11 @@ def _random_config(rng):
 
 
 def test_randomised_scenarios_match_the_oracle(oracle):
-    rng = np.random.default_rng(20260101)
+    # MCR_FUZZ_SEED / MCR_FUZZ_SCENARIOS: longer soaks with other seeds (run by hand on the GPU box; the defaults are the suite's)
+    rng = np.random.default_rng(int(os.environ.get("MCR_FUZZ_SEED", "20260101")))
     n = 256
-    stats = {"paths": 0, "failed": 0, "pre_retirement": 0, "terminal": 0, "scenarios": 0}
-    for k in range(240):
+    stats = {"paths": 0, "failed": 0, "pre_retirement": 0, "terminal": 0, "scenarios": 0, "knife_edge": 0}
+    for k in range(int(os.environ.get("MCR_FUZZ_SCENARIOS", "240"))):
         cfgd = _random_config(rng)
         wm = int(rng.choice([0, 1, 11, 12, 13, 25, int(rng.integers(0, 200))]))
         if k % 10 == 9:  # a family prone to PRE-RETIREMENT annual-tax failure (simulation.py:572-573, :627-634):
@@ -69,20 +72,31 @@ def test_randomised_scenarios_match_the_oracle(oracle):
         g = E.run_batch_host(p, seed, stream, begin, n, wm)
         c = oracle.run_batch(p, seed, stream, begin, n, wm)
         ctx = f"scenario {k}: wm={wm} cfg={cfgd}"
-        assert np.array_equal(g["success"], c["success"]), ctx
-        assert g["counters"].tolist() == c["counters"].tolist(), ctx
-        assert g["ruin_year_bins"].tolist() == c["ruin_year_bins"].tolist(), ctx
-        assert g["wr_obs_counts"].tolist() == c["wr_obs_counts"].tolist(), ctx
+        same_ruin = (g["years_to_ruin"] == c["years_to_ruin"]) | (np.isnan(g["years_to_ruin"]) & np.isnan(c["years_to_ruin"]))
+        flip = (g["success"] != c["success"]) | ~same_ruin     # a different outcome, or the same outcome in a different month
         scale = np.maximum(1.0, np.abs(c["trajectory"]).max(axis=0))   # the path's own money scale
+        if flip.any():
+            # The reference compares dollar amounts with an ABSOLUTE epsilon of 1e-6 (simulation.py:406, :430, :743, :784):
+            # once a path's amounts exceed 2^33 (hyper-inflation corners of this fuzz) that is less than one ulp of the
+            # operands and the reference's own outcome hangs on the last bit of exp().  Only there may flags differ, rarely.
+            assert np.all(scale[flip] >= 2.0 ** 33), (ctx, np.nonzero(flip)[0].tolist(), scale[flip].tolist())
+            stats["knife_edge"] += int(flip.sum())
+        else:
+            assert g["counters"].tolist() == c["counters"].tolist(), ctx
+            assert g["ruin_year_bins"].tolist() == c["ruin_year_bins"].tolist(), ctx
+            assert g["wr_obs_counts"].tolist() == c["wr_obs_counts"].tolist(), ctx
+        keep = ~flip
+        scale = scale[keep]
         for key in ("trajectory", "real_trajectory"):
-            err = np.abs(g[key] - c[key])
-            assert np.all(err <= ABS + REL * np.maximum(np.abs(c[key]), scale)), (ctx, key, float(err.max()))
-        assert np.array_equal(np.isnan(g["withdrawal_rate_trajectory"]), np.isnan(c["withdrawal_rate_trajectory"])), ctx
-        np.testing.assert_allclose(g["withdrawal_rate_trajectory"], c["withdrawal_rate_trajectory"], rtol=1e-8, atol=1e-9, equal_nan=True, err_msg=ctx)
-        np.testing.assert_allclose(g["years_to_ruin"], c["years_to_ruin"], rtol=0, atol=0, equal_nan=True, err_msg=ctx)
+            err = np.abs(g[key][:, keep] - c[key][:, keep])
+            assert np.all(err <= ABS + REL * np.maximum(np.abs(c[key][:, keep]), scale)), (ctx, key, float(err.max()))
+        gw, cw = g["withdrawal_rate_trajectory"][:, keep], c["withdrawal_rate_trajectory"][:, keep]
+        assert np.array_equal(np.isnan(gw), np.isnan(cw)), ctx
+        np.testing.assert_allclose(gw, cw, rtol=1e-8, atol=1e-9, equal_nan=True, err_msg=ctx)
+        np.testing.assert_allclose(g["years_to_ruin"][keep], c["years_to_ruin"][keep], rtol=0, atol=0, equal_nan=True, err_msg=ctx)
         for key in ("start_balance", "final_balance", "first_year_gross_withdrawal", "first_year_real_gross_withdrawal", "inflation_at_retirement"):
-            err = np.abs(g[key] - c[key])
-            assert np.all(err <= ABS + REL * np.maximum(np.abs(c[key]), scale)), (ctx, key, float(err.max()))
+            err = np.abs(g[key][keep] - c[key][keep])
+            assert np.all(err <= ABS + REL * np.maximum(np.abs(c[key][keep]), scale)), (ctx, key, float(err.max()))
         stats["paths"] += n
         stats["scenarios"] += 1
         stats["failed"] += int(n - c["counters"][0])
@@ -91,3 +105,7 @@ def test_randomised_scenarios_match_the_oracle(oracle):
     # the sweep must actually reach the rare branches
     assert stats["failed"] > 5000 and stats["failed"] < stats["paths"] - 5000, stats
     assert stats["pre_retirement"] > 0, stats
+    # 0 with the suite's seed; soaks of 3000-6000 scenarios: 6 / 768 000, 50 / 1 536 000, and 422 / 768 000 when the draw
+    # contains a scenario that lives there (100 % annual tax on both assets at 18 % inflation: seed 777, scenario 2226)
+    assert stats["knife_edge"] <= 1e-3 * stats["paths"], stats
+    print("differential sweep:", stats)
