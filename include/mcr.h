@@ -262,6 +262,14 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
 #define MCR_HELPER_MATH_NEG2LOG 8  /* in[1]=(x as uint32)  out[1]=-2 ln((x+0.5) 2^-32)                */
 #define MCR_HELPER_MATH_SINCOS 9   /* in[1]=(x as uint32)  out[2]=(sin, cos)(2 pi (x+0.5) 2^-32)      */
 #define MCR_HELPER_MATH_DIV_PATH 10 /* in[2]=(a,b)         out[1]=a/b as the path kernel divides (1 Newton step) */
+/* The PATH FORMS of the state-machine helpers — the code the path kernel actually runs (clamps that are provable no-ops
+ * on reachable states dropped, selections as masked moves, compile-time tax variants chosen from the parameter block as
+ * the launcher does).  Inputs must be reachable states: balances and cost bases >= 0, targets >= 0.  Rates, allocation
+ * and the tax systems come from the parameter block. */
+#define MCR_HELPER_WITHDRAW2_PATH 11  /* in[6]=(b1,cb1,target1,b2,cb2,target2) out[8]=(b1,cb1,gross1,net1,b2,cb2,gross2,net2) */
+#define MCR_HELPER_NLV2_PATH 12       /* in[4]=(b1,cb1,b2,cb2) out[2] */
+#define MCR_HELPER_REBALANCE_PATH 13  /* in[4]=(b1,cb1,b2,cb2) out[4] */
+#define MCR_HELPER_ANNUAL_TAX_PATH 14 /* in[6]=(b1,cb1,b2,cb2,g1,g2) out[5]=(b1,cb1,b2,cb2,tax_failed) */
 /* Evaluates helper `which` ON THE DEVICE for n rows (host buffers, row-major). */
 int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out,
                          int64_t n, int device);

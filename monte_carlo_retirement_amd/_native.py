@@ -36,6 +36,10 @@ MCR_HELPER_MATH_SQRT = 7
 MCR_HELPER_MATH_NEG2LOG = 8
 MCR_HELPER_MATH_SINCOS = 9
 MCR_HELPER_MATH_DIV_PATH = 10
+MCR_HELPER_WITHDRAW2_PATH = 11
+MCR_HELPER_NLV2_PATH = 12
+MCR_HELPER_REBALANCE_PATH = 13
+MCR_HELPER_ANNUAL_TAX_PATH = 14
 _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_WITHDRAW: (5, 4),
     MCR_HELPER_NLV: (4, 1),
@@ -48,6 +52,10 @@ _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_MATH_NEG2LOG: (1, 1),
     MCR_HELPER_MATH_SINCOS: (1, 2),
     MCR_HELPER_MATH_DIV_PATH: (2, 1),
+    MCR_HELPER_WITHDRAW2_PATH: (6, 8),
+    MCR_HELPER_NLV2_PATH: (4, 2),
+    MCR_HELPER_REBALANCE_PATH: (4, 4),
+    MCR_HELPER_ANNUAL_TAX_PATH: (6, 5),
 }
 
 

@@ -449,6 +449,46 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
         case MCR_HELPER_MATH_DIV: out[i] = fdiv(in[2 * i], in[2 * i + 1]); break;
         case MCR_HELPER_MATH_DIV_PATH: out[i] = fdiv<false>(in[2 * i], in[2 * i + 1]); break;
         case MCR_HELPER_MATH_SQRT: out[i] = fsqrt(in[i]); break;
+        case MCR_HELPER_WITHDRAW2_PATH: {
+            const double* x = in + 6 * i;
+            const LaneParams L = lane_params(P);
+            double b1 = x[0], c1 = x[1], b2 = x[3], c2 = x[4], g1, n1, g2, n2;
+            if (P.any_real_rate) withdraw2<true>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2);
+            else withdraw2<false>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2);
+            double* o = out + 8 * i;
+            o[0] = b1; o[1] = c1; o[2] = g1; o[3] = n1; o[4] = b2; o[5] = c2; o[6] = g2; o[7] = n2;
+            break;
+        }
+        case MCR_HELPER_NLV2_PATH: {
+            const double* x = in + 4 * i;
+            const LaneParams L = lane_params(P);
+            double v1, v2;
+            if (P.any_real_rate) net_liquidation_values2<true>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2);
+            else net_liquidation_values2<false>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2);
+            out[2 * i] = v1; out[2 * i + 1] = v2;
+            break;
+        }
+        case MCR_HELPER_REBALANCE_PATH: {
+            const double* x = in + 4 * i;
+            double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
+            if (P.any_real_rate) rebalance_path<true>(lane_params(P), b1, c1, b2, c2);
+            else rebalance_path<false>(lane_params(P), b1, c1, b2, c2);
+            out[4 * i + 0] = b1; out[4 * i + 1] = c1; out[4 * i + 2] = b2; out[4 * i + 3] = c2;
+            break;
+        }
+        case MCR_HELPER_ANNUAL_TAX_PATH: {
+            const double* x = in + 6 * i;
+            double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
+            const LaneParams L = lane_params(P);
+            bool tf;
+            if (P.any_real_rate) tf = P.any_annual_tax ? annual_gain_taxes<false, true, true>(P, L, b1, c1, b2, c2, x[4], x[5])
+                                                       : annual_gain_taxes<false, true, false>(P, L, b1, c1, b2, c2, x[4], x[5]);
+            else tf = P.any_annual_tax ? annual_gain_taxes<false, false, true>(P, L, b1, c1, b2, c2, x[4], x[5])
+                                       : annual_gain_taxes<false, false, false>(P, L, b1, c1, b2, c2, x[4], x[5]);
+            out[5 * i + 0] = b1; out[5 * i + 1] = c1; out[5 * i + 2] = b2; out[5 * i + 3] = c2;
+            out[5 * i + 4] = tf ? 1.0 : 0.0;
+            break;
+        }
         case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab, MathRegs::literals()); break;
         case MCR_HELPER_MATH_SINCOS: {
             double sn, cs;
@@ -1171,6 +1211,10 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
         case MCR_HELPER_MATH_EXP: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_DIV: n_in = 2; n_out = 1; break;
         case MCR_HELPER_MATH_DIV_PATH: n_in = 2; n_out = 1; break;
+        case MCR_HELPER_WITHDRAW2_PATH: n_in = 6; n_out = 8; break;
+        case MCR_HELPER_NLV2_PATH: n_in = 4; n_out = 2; break;
+        case MCR_HELPER_REBALANCE_PATH: n_in = 4; n_out = 4; break;
+        case MCR_HELPER_ANNUAL_TAX_PATH: n_in = 6; n_out = 5; break;
         case MCR_HELPER_MATH_SQRT: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_NEG2LOG: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_SINCOS: n_in = 1; n_out = 2; break;
@@ -1180,7 +1224,8 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
     if (n == 0) return MCR_OK;
     DevParams d;
     std::memset(&d, 0, sizeof(d));
-    if (which == MCR_HELPER_REBALANCE || which == MCR_HELPER_ANNUAL_TAX) {
+    if (which == MCR_HELPER_REBALANCE || which == MCR_HELPER_ANNUAL_TAX || which == MCR_HELPER_WITHDRAW2_PATH ||
+        which == MCR_HELPER_NLV2_PATH || which == MCR_HELPER_REBALANCE_PATH || which == MCR_HELPER_ANNUAL_TAX_PATH) {
         if (!p) { set_error("helper %d needs params", which); return MCR_ERR_INVALID_ARG; }
         rc = derive_params(p, 0, &d);
         if (rc != MCR_OK) return rc;
