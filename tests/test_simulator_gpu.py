@@ -5,6 +5,7 @@ pandas goldens, and the full search vs the reference's recorded search."""
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import pandas as pd
@@ -455,3 +456,80 @@ def test_bracketed_row_quantiles_at_the_default_threshold():
     assert A.last_fallback_rows() == 0
     for r in range(3):
         assert np.array_equal(got9[r], np.quantile(rows[r][~np.isnan(rows[r])], nine)), r
+
+
+def _random_row(rng, n):
+    """One row from a menu of shapes that stress the bracketed route differently (scale, sign, ties, NaNs, order)."""
+    kind = int(rng.integers(0, 12))
+    scale = 10.0 ** rng.uniform(-6, 12)
+    if kind == 0:
+        x = rng.normal(rng.normal(0, 3) * scale, scale, n)
+    elif kind == 1:
+        x = rng.lognormal(rng.uniform(-3, 15), rng.uniform(0.1, 3), n) * (-1.0 if rng.random() < 0.3 else 1.0)
+    elif kind == 2:
+        x = rng.integers(0, int(rng.integers(2, 2000)), n).astype(float) * scale          # ties, few to many distinct values
+    elif kind == 3:
+        x = np.where(rng.random(n) < rng.uniform(0.05, 0.95), 0.0, rng.lognormal(5, 2, n))  # a spike at zero + a tail
+    elif kind == 4:
+        x = np.sort(rng.normal(0, scale, n))[:: (1 if rng.random() < 0.5 else -1)]         # monotone
+    elif kind == 5:
+        x = rng.normal(0, 1, n) * 10.0 ** rng.integers(-12, 13, n)                        # every magnitude, both signs
+    elif kind == 6:
+        x = rng.choice([-np.inf, np.inf, 0.0, -0.0, 5e-324, -5e-324, 1.0, -1.0, scale], n)
+    elif kind == 7:
+        x = np.full(n, rng.normal(0, scale))                                              # constant
+    elif kind == 8:
+        x = np.concatenate([np.full(n // 3, -scale), rng.normal(0, scale, n - 2 * (n // 3)), np.full(n // 3, scale)])
+        rng.shuffle(x)                                                                    # two giant ties around a continuum
+    elif kind == 9:
+        x = rng.standard_t(2, n) * scale                                                  # heavy tails
+    elif kind == 10:
+        x = rng.uniform(-scale, scale, n).round(int(rng.integers(0, 3)))
+    else:
+        x = np.where(np.arange(n) < int(rng.integers(1, n)), rng.normal(-5 * scale, scale, n), rng.normal(5 * scale, scale, n))  # regime change
+    if rng.random() < 0.35:                                                               # NaNs: scattered, leading, or nearly all
+        mode = int(rng.integers(0, 3))
+        if mode == 0:
+            x = np.where(rng.random(n) < rng.uniform(0.01, 0.6), np.nan, x)
+        elif mode == 1:
+            x[: int(rng.integers(1, n))] = np.nan
+        else:
+            keep = rng.integers(0, n, int(rng.integers(1, 50)))
+            y = np.full(n, np.nan); y[keep] = x[keep]; x = y
+    return x
+
+
+def test_bracketed_row_quantiles_random_shapes(monkeypatch):
+    """Randomised shapes for the bracketed route (forced through MCR_RQ_BRACKET_MIN_N): row length, stride, row count,
+    row contents and quantile set all drawn; every entry must equal pandas' bit for bit whether the row was decided on
+    its brackets or fell back.  (pandas, which the reference calls — simulation.py:1059-1113 —, not np.quantile: for a q
+    that is not a short binary fraction NumPy's own virtual index n q + (1 - q) - 1 rounds differently from the
+    (n - 1) q pandas ends up with, and the last bits of the interpolation follow.)
+    MCR_RQ_FUZZ_SEED / MCR_RQ_FUZZ_ROUNDS lengthen it for soaks by hand."""
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    rng = np.random.default_rng(int(os.environ.get("MCR_RQ_FUZZ_SEED", "20260102")))
+    monkeypatch.setenv("MCR_RQ_BRACKET_MIN_N", "1")
+    decided = fell_back = 0
+    for _ in range(int(os.environ.get("MCR_RQ_FUZZ_ROUNDS", "8"))):
+        n = int(rng.choice([4096, 4097, 5000, 70_000, int(rng.integers(4096, 400_000)), int(rng.integers(400_000, 3_000_000))]))
+        stride = n + int(rng.choice([0, 1, 2, 7, 64]))
+        n_rows = int(rng.integers(1, 12)) if n < 1_000_000 else int(rng.integers(1, 5))
+        rows = np.full((n_rows, stride), -7.0)
+        for r in range(n_rows):
+            rows[r, :n] = _random_row(rng, n)
+        k = int(rng.integers(1, 16))
+        qs = tuple(sorted(set(np.round(rng.uniform(0, 1, k), int(rng.integers(1, 6))).tolist() + ([0.0] if rng.random() < 0.2 else []) + ([1.0] if rng.random() < 0.2 else []))))[:15]
+        got, counts = A.row_quantiles(torch.as_tensor(rows, device="cuda"), n, qs)
+        n_fb = A.last_fallback_rows()
+        assert n_fb >= 0, (n, qs)                     # the bracketed route was taken
+        fell_back += n_fb
+        decided += n_rows - n_fb
+        exp = pd.DataFrame(rows[:, :n].T).quantile(list(qs), axis=0).T.to_numpy()
+        for r in range(n_rows):
+            assert np.array_equal(got[r], exp[r], equal_nan=True), (n, stride, r, qs, got[r].tolist(), exp[r].tolist())
+            assert counts[r] == int((~np.isnan(rows[r, :n])).sum())
+    assert decided > 0
+    print("bracketed route, random shapes: rows decided on their brackets", decided, "fell back", fell_back)
