@@ -533,3 +533,36 @@ def test_bracketed_row_quantiles_random_shapes(monkeypatch):
             assert counts[r] == int((~np.isnan(rows[r, :n])).sum())
     assert decided > 0
     print("bracketed route, random shapes: rows decided on their brackets", decided, "fell back", fell_back)
+
+
+def test_shared_accumulation_probes_random_scenarios():
+    """Randomised: scenario (the differential test's generator: every tax system, up to 6 income streams, extreme
+    rates), candidate set (1-40 months from 0 to 300, unsorted, with duplicates), path range and batch size all drawn.
+    mcr_probe_months_rng must count exactly what one full launch per candidate counts.
+    MCR_PROBE_FUZZ_SEED / MCR_PROBE_FUZZ_ROUNDS lengthen it for soaks by hand."""
+    from monte_carlo_retirement_amd import params_from_config
+    from monte_carlo_retirement_amd import engine as E
+    from test_gpu_differential import _random_config
+
+    rng = np.random.default_rng(int(os.environ.get("MCR_PROBE_FUZZ_SEED", "20260103")))
+    shared = 0
+    for _ in range(int(os.environ.get("MCR_PROBE_FUZZ_ROUNDS", "12"))):
+        cfgd = _random_config(rng)
+        params = params_from_config(Config(**cfgd))
+        n = int(rng.choice([1, 63, 64, 65, 257, 1000, int(rng.integers(1, 6000))]))
+        begin = int(rng.choice([0, 7, 2**32 - 100, 2**40]))
+        seed, stream = int(rng.integers(0, 2**63)), int(rng.integers(2))
+        k = int(rng.integers(1, 41))
+        top = int(rng.choice([12, 40, 130, 300]))
+        months = [int(m) for m in rng.integers(0, top + 1, k)]
+        if rng.random() < 0.3:
+            months = sorted(set(months))
+        got = E.probe_months(params, seed, stream, begin, n, months).cpu().tolist()
+        exp = []
+        for m in months:
+            b = E.DeviceBatch(params, m, n, want="count")
+            b.launch(seed, stream, begin)
+            exp.append(b.counters.cpu().tolist())
+        assert got == exp, (cfgd, seed, stream, begin, n, months)
+        shared += 2 <= len(set(months)) <= 32
+    assert shared > 0
