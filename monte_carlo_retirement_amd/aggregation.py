@@ -134,7 +134,9 @@ def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int, 
     floor = int(os.environ.get("MCR_RQ_SHARDED_BRACKET_MIN_N", _SHARDED_BRACKET_MIN_TOTAL))
     use_bracket = grouped and n_total >= floor and 2 * len(q) < 32 and world <= 64
     if use_bracket:
-        short = torch.tensor([1 if n_local < min(_SHARD_MIN_LOCAL, floor) else 0], dtype=torch.int32, device=dev)
+        # (never below the library's own minimum — 4096 entries on rank 0, whose first sample seeds the brackets — whatever
+        #  the override says: the library checks that on rank 0 only, and a route must be taken by every rank or by none)
+        short = torch.tensor([1 if n_local < max(4096, min(_SHARD_MIN_LOCAL, floor)) else 0], dtype=torch.int32, device=dev)
         reduce_counts(short)
         use_bracket = int(short.item()) == 0
     if use_bracket:

@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from monte_carlo_retirement_amd import Config, params_from_config  # noqa: E402
 from monte_carlo_retirement_amd import aggregation as A  # noqa: E402
@@ -88,6 +89,37 @@ def main():
     res["bracket_mid_equal"] = bool(np.array_equal(gm, expm, equal_nan=True))
     res["bracket_mid_counts"] = cm.tolist() == (~np.isnan(mid)).sum(axis=1).tolist()
     del os.environ["MCR_RQ_SHARDED_BRACKET_MIN_N"]
+
+    # ---- (1c) randomised shapes through the sharded routes (every rank draws the same slab from the same seed and takes
+    # its shard): total length from just above the bracketed route's minimum shard to ~1.2e6, 1-8 rows from the menu of
+    # tests/test_simulator_gpu.py::_random_row, 1-15 quantiles; must equal pandas on the whole slab bit for bit.
+    # MCR_SHARD_FUZZ_SEED / MCR_SHARD_FUZZ_ROUNDS lengthen it for soaks by hand.
+    from test_simulator_gpu import _random_row
+
+    os.environ["MCR_RQ_SHARDED_BRACKET_MIN_N"] = "1"
+    fr = np.random.default_rng(int(os.environ.get("MCR_SHARD_FUZZ_SEED", "20260104")))
+    fuzz_bad, fuzz_bracket_calls = [], 0
+    for it in range(int(os.environ.get("MCR_SHARD_FUZZ_ROUNDS", "6"))):
+        n_f = int(fr.choice([world * 65536, world * 65536 + 1, int(fr.integers(world * 65536, 1_200_000)), int(fr.integers(1000, world * 65536))]))
+        rows_f = int(fr.integers(1, 9))
+        slab_f = np.empty((rows_f, n_f))
+        for r in range(rows_f):
+            slab_f[r] = _random_row(fr, n_f)
+        k = int(fr.integers(1, 16))
+        qs = tuple(sorted(set(np.round(fr.uniform(0, 1, k), int(fr.integers(1, 6))).tolist() + ([0.0] if fr.random() < 0.2 else []) + ([1.0] if fr.random() < 0.2 else []))))[:15]
+        f0, fc = D.shard_range(n_f, rank, world)
+        fstride = max(64, (fc + int(fr.choice([0, 1, 63]))))
+        flocal = torch.full((rows_f, fstride), -7.0, dtype=torch.float64, device="cuda")
+        flocal[:, :fc] = torch.as_tensor(slab_f[:, f0:f0 + fc], device="cuda")
+        gf, cf = D.sharded_row_quantiles(flocal, fc, qs)
+        fuzz_bracket_calls += A.last_fallback_rows() >= 0
+        expf = pd.DataFrame(slab_f.T).quantile(list(qs), axis=0).T.to_numpy()
+        if not np.array_equal(gf, expf, equal_nan=True) or cf.tolist() != (~np.isnan(slab_f)).sum(axis=1).tolist():
+            fuzz_bad.append((it, n_f, rows_f, qs))
+        del flocal
+    del os.environ["MCR_RQ_SHARDED_BRACKET_MIN_N"]
+    res["fuzz_bad"] = [str(b) for b in fuzz_bad]
+    res["fuzz_bracket_calls"] = int(fuzz_bracket_calls)
 
     # ---- (2) sharded bands vs one process over the whole range
     with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
