@@ -566,3 +566,47 @@ def test_shared_accumulation_probes_random_scenarios():
         assert got == exp, (cfgd, seed, stream, begin, n, months)
         shared += 2 <= len(set(months)) <= 32
     assert shared > 0
+
+
+def test_success_histogram_random_inputs():
+    """np.histogram(values[success], bins) on randomised inputs: sizes from 1 to 3e6, value scales from 1e-9 to 1e13,
+    heavy ties on the edges (zeros — the final balance of a ruined path — and the maximum), cohort fractions from none
+    to all, 1 to 400 bins, fixed and derived ranges.  Counts must be identical, edges bit-equal.
+    MCR_HIST_FUZZ_SEED / MCR_HIST_FUZZ_ROUNDS lengthen it for soaks by hand."""
+    import torch
+
+    from monte_carlo_retirement_amd import aggregation as A
+
+    rng = np.random.default_rng(int(os.environ.get("MCR_HIST_FUZZ_SEED", "20260105")))
+    for _ in range(int(os.environ.get("MCR_HIST_FUZZ_ROUNDS", "25"))):
+        n = int(rng.choice([1, 2, 63, 64, 65, 1000, int(rng.integers(1, 100_000)), int(rng.integers(100_000, 3_000_000))]))
+        scale = 10.0 ** rng.uniform(-9, 13)
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            v = rng.lognormal(0, rng.uniform(0.1, 2.5), n) * scale
+        elif kind == 1:
+            v = np.where(rng.random(n) < rng.uniform(0, 0.9), 0.0, rng.lognormal(0, 1, n) * scale)   # ruined paths: exact zeros
+        elif kind == 2:
+            v = rng.integers(0, int(rng.integers(1, 50)), n).astype(float) * scale                    # values ON bin edges
+        elif kind == 3:
+            v = np.full(n, scale)                                                                     # degenerate range
+        else:
+            v = rng.uniform(0, scale, n)
+            v[rng.integers(0, n, max(1, n // 10))] = v.max()                                           # ties at the right edge
+        ok = (rng.random(n) < rng.choice([0.0, 0.02, 0.5, 0.97, 1.0])).astype(np.uint8)
+        bins = int(rng.choice([1, 2, 7, 60, 100, 400]))
+        sel = v[ok.astype(bool)]
+        rng_arg = None
+        if rng.random() < 0.3 and sel.size:
+            lo = float(sel.min() - rng.uniform(0, 1) * scale)
+            rng_arg = (lo, float(sel.max() + rng.uniform(0, 1) * scale))
+        got, edges = A.success_histogram(torch.as_tensor(v, device="cuda"), torch.as_tensor(ok, device="cuda"), bins, value_range=rng_arg)
+        if sel.size == 0:
+            assert got.sum() == 0
+            continue
+        try:
+            exp, exp_edges = np.histogram(sel, bins=bins, range=rng_arg)
+        except ValueError:            # "Too many bins for data range": numpy (hence the reference) refuses; nothing to match
+            continue
+        assert got.tolist() == exp.tolist(), (n, kind, bins, rng_arg, scale)
+        assert np.array_equal(edges, exp_edges), (n, kind, bins, rng_arg)
