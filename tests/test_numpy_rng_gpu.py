@@ -4,6 +4,8 @@ results within the path tolerance, Success flags and the search identical."""
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
@@ -20,6 +22,9 @@ REL, ABS = 1e-9, 1e-6
 def test_shock_rows_equal_numpy_bit_for_bit():
     """default_rng(seed).standard_normal((n, 3)) + rho mix (simulation.py:452-466), on the device."""
     seeds = np.array([0, 1, 42, 3735928559, 2**32 - 1, 777], dtype=np.uint32)
+    extra = int(os.environ.get("MCR_NPRNG_FUZZ_SEEDS", "0"))    # soak by hand: that many more random seeds (1.2e4 draws each)
+    if extra:
+        seeds = np.concatenate([seeds, np.random.default_rng(int(os.environ.get("MCR_NPRNG_FUZZ_SEED", "1"))).integers(0, 2**32, extra, dtype=np.uint64).astype(np.uint32)])
     n_months, rho = 2000, 0.3
     got = E.draw_shocks_host(N.numpy_rng(0), 1, 0, len(seeds), n_months, rho, path_seeds=seeds)
     exact = total = 0
