@@ -312,3 +312,60 @@ def test_plain_c_caller_equals_the_python_path(tmp_path):
     ref = E.run_batch_host(params_from_config(cfg), seed, 1, 0, n, wm, want_summary=False, want_trajectories=False)
     assert int(fields["paths"]) == n == int(ref["counters"][1])
     assert int(fields["success"]) == int(ref["counters"][0])
+
+
+def test_any_subset_of_output_pointers():
+    """`mcr_outputs`: "Any pointer may be NULL = not requested; the kernel variant is chosen from what is requested".
+    Random subsets of the 13 output pointers (incl. none at all, one trajectory without the summary, bins without
+    counters), strides larger than n, ragged n, both streams, through the raw C ABI: every requested array equals the
+    full run's, bit for bit; padding beyond n and arrays that were not requested stay untouched.
+    MCR_OUT_FUZZ_SEED / MCR_OUT_FUZZ_ROUNDS lengthen it for soaks by hand."""
+    lib = N.load_library()
+    rng = np.random.default_rng(int(os.environ.get("MCR_OUT_FUZZ_SEED", "20260106")))
+    cfgs = load_golden("paths_injected.json")
+    per_path = list(E.SUMMARY_FIELDS) + ["success"]
+    traj = ["trajectory", "real_trajectory", "withdrawal_rate_trajectory"]
+    vecs = ["counters", "wr_obs_counts", "ruin_year_bins"]
+    for _ in range(int(os.environ.get("MCR_OUT_FUZZ_ROUNDS", "40"))):
+        g = cfgs[int(rng.integers(len(cfgs)))]
+        p = params_from_config(Config(**g["cfg"]))
+        wm = int(rng.choice([0, 1, 12, 13, g["working_months"]]))
+        n = int(rng.choice([1, 63, 64, 65, 300, int(rng.integers(1, 1500))]))
+        stride = n + int(rng.choice([0, 1, 64, 100]))
+        seed, stream, begin = int(rng.integers(0, 2**63)), int(rng.integers(2)), int(rng.choice([0, 5, 2**32 - 7]))
+        full = E.run_batch_host(p, seed, stream, begin, n, wm)
+        sz = E.query_sizes(p, wm)
+        want = {k: bool(rng.random() < 0.5) for k in per_path + traj + vecs}
+        if rng.random() < 0.1:
+            want = {k: False for k in want}
+        SENT = -12345.0
+        bufs = {}
+        o = N.McrOutputs()
+        o.path_stride = stride
+        for k in per_path:
+            bufs[k] = np.full(n + 3, 77, dtype=np.uint8) if k == "success" else np.full(n + 3, SENT)
+        for k, rows in (("trajectory", sz.trajectory_len), ("real_trajectory", sz.trajectory_len), ("withdrawal_rate_trajectory", sz.retirement_years)):
+            bufs[k] = np.full((rows, stride), SENT)
+        bufs["counters"] = np.zeros(N.MCR_N_COUNTERS, dtype=np.uint64)
+        bufs["wr_obs_counts"] = np.zeros(sz.retirement_years, dtype=np.uint64)
+        bufs["ruin_year_bins"] = np.zeros(sz.ruin_bins, dtype=np.uint64)
+        for k, w in want.items():
+            if w:
+                setattr(o, k, bufs[k].ctypes.data)
+        rc = lib.mcr_run_batch_host(C.byref(p), seed, stream, begin, n, wm, None, C.byref(o), 0)
+        assert rc == 0, (N.last_error(), want)
+        ctx = (g["name"], wm, n, stride, want)
+        for k in per_path:
+            if want[k]:
+                assert np.array_equal(bufs[k][:n], full[k], equal_nan=True), (k, ctx)
+                assert np.all(bufs[k][n:] == (77 if k == "success" else SENT)), (k, ctx)
+            else:
+                assert np.all(bufs[k] == (77 if k == "success" else SENT)), (k, ctx)
+        for k in traj:
+            if want[k]:
+                assert np.array_equal(bufs[k][:, :n], full[k], equal_nan=True), (k, ctx)
+                assert np.all(bufs[k][:, n:] == SENT), (k, ctx)
+            else:
+                assert np.all(bufs[k] == SENT), (k, ctx)
+        for k in vecs:
+            assert bufs[k].tolist() == (full[k].tolist() if want[k] else [0] * bufs[k].size), (k, ctx)
