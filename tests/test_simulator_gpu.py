@@ -610,3 +610,32 @@ def test_success_histogram_random_inputs():
             continue
         assert got.tolist() == exp.tolist(), (n, kind, bins, rng_arg, scale)
         assert np.array_equal(edges, exp_edges), (n, kind, bins, rng_arg)
+
+
+def test_batched_search_equals_one_probe_at_a_time_on_random_scenarios():
+    """The search on randomised scenarios (the differential test's generator + random target probability, starting
+    month and paths per probe), with 1, 2, 4 or 8 speculation slots: result, probe curve and progress events must equal
+    those of strictly one launch per probe — including searches that hit the reference's upper bound or find the
+    target at month 0.  MCR_SEARCH_FUZZ_SEED / MCR_SEARCH_FUZZ_ROUNDS lengthen it for soaks by hand."""
+    from test_gpu_differential import _random_config
+
+    rng = np.random.default_rng(int(os.environ.get("MCR_SEARCH_FUZZ_SEED", "20260107")))
+    found = 0
+    for _ in range(int(os.environ.get("MCR_SEARCH_FUZZ_ROUNDS", "10"))):
+        cfgd = _random_config(rng)
+        cfgd.update(num_simulations_search=int(rng.choice([1, 50, 300, 2000])), num_simulations_main=10,
+                    target_probability=float(rng.choice([1.0, 50.0, 90.0, 97.0, 99.9, 100.0])),
+                    starting_working_months_search=int(rng.choice([0, 0, 12, 100, 400])), seed=int(rng.integers(0, 2**31)))
+        cfg = Config(**cfgd)
+        slots = int(rng.choice([1, 2, 4, 8]))
+        ea, eb = [], []
+        a = RetirementMonteCarloSimulator(cfg)
+        a._speculation_slots = lambda n, s=slots: s
+        b = RetirementMonteCarloSimulator(cfg)
+        many_b = b._probe_many
+        b._probe_many = lambda months, n, f=many_b: {m: f([m], n)[m] for m in months}
+        ra = a.find_minimum_working_months(verbose=False, progress_callback=ea.append)
+        rb = b.find_minimum_working_months(verbose=False, progress_callback=eb.append)
+        assert ra == rb and ea == eb, (cfgd, slots, ra, rb)
+        found += ra[0] is not None
+    assert found > 0
