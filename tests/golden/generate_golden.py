@@ -518,7 +518,35 @@ def gen_search():
                                                               monthly_expenses=5_000.0, retirement_years=30,
                                                               inv1_returns_mean=0.10, inv1_returns_volatility=0.12,
                                                               inflation_rate_mean=0.04, inflation_rate_volatility=0.015,
-                                                              num_simulations_search=60, target_probability=85.0), 123)]:
+                                                              num_simulations_search=60, target_probability=85.0), 123),
+                             # round 2: more of the search's branches on the reference itself —
+                             # annual-gains tax on both assets + income streams, a late starting month
+                             ("ANNUAL_TAX_search", base_test_config(initial_balance=150_000.0, monthly_contribution=2_500.0,
+                                                                    contribution_growth_rate_annual=0.03, monthly_expenses=6_000.0,
+                                                                    retirement_years=25, inv1_annual_tax_on_gains_rate=0.15,
+                                                                    inv2_annual_tax_on_gains_rate=0.15, inv1_returns_mean=0.09,
+                                                                    inv1_returns_volatility=0.16, inflation_rate_mean=0.035,
+                                                                    inflation_rate_volatility=0.012, equity_inflation_correlation=-0.4,
+                                                                    num_simulations_search=40, target_probability=90.0,
+                                                                    starting_working_months_search=60,
+                                                                    other_income_streams=[
+                                                                        {"name": "pension", "monthly_amount_today": 1500.0, "start_at_age": 67.0,
+                                                                         "duration_years": None, "inflation_indexed": True, "tax_rate": 0.1},
+                                                                        {"name": "rent", "monthly_amount_today": 800.0, "start_at_age": 45.5,
+                                                                         "duration_years": 12, "inflation_indexed": False, "tax_rate": 0.2}]), 2024),
+                             # the target is met without working at all
+                             ("RICH_search", base_test_config(initial_balance=5_000_000.0, monthly_expenses=3_000.0, retirement_years=20,
+                                                              num_simulations_search=30, target_probability=95.0), 7),
+                             # the target is out of reach: the search runs into its upper bound
+                             ("HOPELESS_search", base_test_config(initial_balance=1_000.0, monthly_contribution=10.0, monthly_expenses=9_000.0,
+                                                                  retirement_years=30, inv1_returns_mean=0.01, inv1_returns_volatility=0.05,
+                                                                  num_simulations_search=12, target_probability=99.0), 11),
+                             # few paths per probe and a high target: the probabilities are coarse and not monotone,
+                             # the verification window below the bisection's answer matters
+                             ("COARSE_search", base_test_config(initial_balance=80_000.0, monthly_contribution=1_800.0, monthly_expenses=3_500.0,
+                                                                retirement_years=28, inv1_returns_volatility=0.22, allocation_inv1_pct=0.85,
+                                                                inv1_realized_gains_tax_rate=0.15, inv1_use_realized_gains_tax_system=True,
+                                                                num_simulations_search=16, target_probability=93.0), 31337)]:
         sim = make_sim(cfgd, seed=seed)
         inject_engine_shocks(sim, seed)
         events = []

@@ -149,7 +149,7 @@ def test_search_unreachable_target_returns_minus_one():
     assert months == -1 and prob == pytest.approx(80.0) and curve[-1]["working_months"] == 70 * 12
 
 
-@pytest.mark.parametrize("idx", [0, 1])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5])
 def test_search_replays_reference_run(idx):
     """Feed the probabilities the REFERENCE measured (search.json) through a fake backend: the
     driver must probe the same months in the same order, emit the same events and result."""
@@ -188,7 +188,7 @@ def test_config_schema_equals_the_references():
     assert mine == load_golden("config_schema.json")
 
 
-@pytest.mark.parametrize("idx", [0, 1])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("slots", [1, 3, 5, 16])
 def test_search_batches_candidates_without_changing_the_replay(idx, slots):
     """The GPU route evaluates candidates ahead of time, several per call (`_probe_many`).  With the
@@ -228,4 +228,4 @@ def test_search_batches_candidates_without_changing_the_replay(idx, slots):
         # without speculation only the verification window is batched
         assert set(flat) == set(table)
     else:
-        assert len(calls) < len(table)                      # fewer launches than probes
+        assert len(calls) < len(table) or len(table) == 1   # fewer launches than probes (a one-probe search has nothing to batch)
