@@ -150,17 +150,38 @@ def test_kernel_vs_oracle_100k(oracle, name):
     """Identical counters, 1e5 paths: Success flags identical, summary fields within REL."""
     g = [x for x in load_golden("paths_injected.json") if x["name"] == name][0]
     p = _params(g["cfg"])
-    n = 100_000
+    n = int(os.environ.get("MCR_ORACLE_PATHS", "100000"))          # soak by hand: more paths, another range
+    first = int(os.environ.get("MCR_ORACLE_FIRST_PATH", "0"))
     sid = STREAM_ID[g["stream"]]
-    gpu = E.run_batch_host(p, g["seed"], sid, 0, n, g["working_months"], want_trajectories=False)
-    cpu = oracle.run_batch(p, g["seed"], sid, 0, n, g["working_months"], want_trajectories=False)
+    gpu = E.run_batch_host(p, g["seed"], sid, first, n, g["working_months"], want_trajectories=False)
+    threads = 16 if n > 200_000 else 1
+    per = (n + threads - 1) // threads
+    parts = [None] * threads
+
+    def work(t):
+        b = first + t * per
+        parts[t] = oracle.run_batch(p, g["seed"], sid, b, max(0, min(per, first + n - b)), g["working_months"], want_trajectories=False)
+
+    import threading
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    cpu = {k: (sum(q[k] for q in parts) if k in ("counters", "ruin_year_bins", "wr_obs_counts") else np.concatenate([q[k] for q in parts]))
+           for k in parts[0]}
     flips = int((gpu["success"] != cpu["success"]).sum())
     assert flips == 0, f"{flips} flipped Success flags out of {n}"
     assert gpu["counters"].tolist() == cpu["counters"].tolist()
     assert gpu["ruin_year_bins"].tolist() == cpu["ruin_year_bins"].tolist()
     assert gpu["wr_obs_counts"].tolist() == cpu["wr_obs_counts"].tolist()
+    # 1e-9 relative to the PATH'S money scale (its balance at retirement): a final balance that is a small remainder of
+    # multi-million flows carries the absolute error of those flows (1 path in 2e6 of a soak: 1e-5 dollars on 2 641)
+    scale = np.maximum(np.abs(cpu["start_balance"]), 1.0)
     for k in E.SUMMARY_FIELDS:
-        np.testing.assert_allclose(gpu[k], cpu[k], rtol=REL, atol=ABS, equal_nan=True, err_msg=k)
+        both_nan = np.isnan(gpu[k]) & np.isnan(cpu[k])
+        err = np.where(both_nan, 0.0, np.abs(gpu[k] - cpu[k]))
+        assert np.all(err <= ABS + REL * np.maximum(np.abs(np.nan_to_num(cpu[k])), scale)), (k, float(np.nanmax(err)))
 
 
 def test_sharding_and_ragged_sizes_are_bit_identical():
