@@ -64,7 +64,9 @@ __device__ __forceinline__ unsigned long long f64_bits(double x) { return (unsig
 __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) { *reinterpret_cast<unsigned long long*>(p) = bits; }
 
 // __launch_bounds__(256, 4): the kernel saturates the fp64 VALU with 4 waves per SIMD (measured by capping
-// residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.
+// residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.  The count-only Philox
+// variants are held to 6 waves per SIMD (<= 80 VGPRs): the BASELINE workload of 1e6 paths is 15.26 waves per SIMD, and
+// with 5 resident waves that is 5 + 5 + 5 + a lone fourth round (+9 %); the annual-tax variant sat at 81.
 // INJ = true: shocks come from io.injected (the parity hook) instead of the RNG; only instantiated with MODE 2
 // (every output is null-checked), so the hot variants carry neither the injection branches nor their registers.
 // PHASE 0: the whole path.  PHASE 1 / 2 split it at retirement for the search (simulation.py:1180-1194 re-simulates the
@@ -75,7 +77,7 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 #define MCR_K1_WAVES_ATTR
 #endif
 template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0>
-__global__ __launch_bounds__(kBlock, 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
+__global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
     // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
