@@ -44,6 +44,7 @@ struct DevParams {
     double ainf, binf;                 // inflation: idem
     double aprem, bprem;               // inv2 premium over inflation: idem
     double rho, rho_c;                 // rho, sqrt(max(0, 1 - rho^2))               (:460-464)
+    double binf_rho, binf_rho_c;       // binf * rho, binf * rho_c: the inflation log-return straight from two normals (growth_rows2)
     int32_t working_months, retirement_years, total_months, shock_rows;
     int32_t num_working_years, trajectory_len, n_streams, n_lock_slots;
     int32_t contrib_grows;             // contribution_growth_rate_annual > 0        (:516)
@@ -105,6 +106,13 @@ __device__ __forceinline__ void bm_pair(uint32_t xr, uint32_t xa, const double* 
     sincos_u32<true>(xa, tab, R, s, c);
     zc = r * c;
     zs = r * s;
+}
+
+// The same pair as its PARTS: radius r and the angle's (cos, sin), the two normals being r cos and r sin.  growth_rows2
+// folds the products into the log-returns instead of forming the normals first.
+__device__ __forceinline__ void bm_parts(uint32_t xr, uint32_t xa, const double* tab, const MathRegs& R, double& r, double& c, double& s) {
+    r = fsqrt(neg2_log_u32(xr, tab, R));
+    sincos_u32<true>(xa, tab, R, s, c);
 }
 
 struct ShockGen {      // per-lane carry between consecutive rows
@@ -180,31 +188,44 @@ struct PairCarry { uint32_t w2, w3; };
 template <int HALF>
 __device__ __forceinline__ void growth_rows2(const DevParams& P, const MathRegs& M, uint64_t seed, uint32_t stream_id, uint64_t path,
                                              uint32_t t, const double* tab, double* stage, PairCarry& C) {
-    double n[6];
+    // pair i: radius rad[i], trig[2 i] = cos, trig[2 i + 1] = sin; normal j of the half = rad[j >> 1] * trig[j]
+    double rad[3], trig[6];
     uint32_t x[4];
     if (HALF == 0) {
         philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        bm_pair(x[0], x[1], tab, M, n[0], n[1]);
-        bm_pair(x[2], x[3], tab, M, n[2], n[3]);
+        bm_parts(x[0], x[1], tab, M, rad[0], trig[0], trig[1]);
+        bm_parts(x[2], x[3], tab, M, rad[1], trig[2], trig[3]);
         philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t + 1u, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        bm_pair(x[0], x[1], tab, M, n[4], n[5]);
+        bm_parts(x[0], x[1], tab, M, rad[2], trig[4], trig[5]);
         C.w2 = x[2]; C.w3 = x[3];
     } else {
-        bm_pair(C.w2, C.w3, tab, M, n[0], n[1]);
+        bm_parts(C.w2, C.w3, tab, M, rad[0], trig[0], trig[1]);
         philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), 3u * t + 2u, stream_id, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        bm_pair(x[0], x[1], tab, M, n[2], n[3]);
-        bm_pair(x[2], x[3], tab, M, n[4], n[5]);
+        bm_parts(x[0], x[1], tab, M, rad[1], trig[2], trig[3]);
+        bm_parts(x[2], x[3], tab, M, rad[2], trig[4], trig[5]);
     }
+    // The three log-returns of a month, x = a + b z (:473) with z_inf = rho n0 + rho_c n1 (:461-464), written on the
+    // PARTS of the normals: x_eq = (b1 r) t + a1, x_inf = (binf rho r0) t0 + ((binf rho_c r1) t1 + a_inf), x_prem
+    // likewise — the same eight fp64 operations as "normals first", but every FMA now has ONE scalar operand (a VOP3
+    // instruction reads at most one: b z + a with a and b both in SGPRs cost two v_mov_b32 per evaluation, six a month).
+    // The product is associated differently from shock_row_seq's (b (r t) vs (b r) t): the arguments of exp agree to
+    // ~1e-17, a tenth of an ulp of the growth factor.
+    // (v_fma_f64 with the SCALAR addend spelled out: left to itself the compiler picks the two-address v_fmac_f64 and
+    //  copies the scalar into its accumulator first — the very two v_mov_b32 this arrangement is there to avoid)
+    auto fma_vvs = [](double a, double b, double c_scalar) {
+        double d;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+        return d;
+    };
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const double z_eq = n[3 * r], z_prem = n[3 * r + 2];
-        const double z_inf = __builtin_fma(P.rho, n[3 * r], P.rho_c * n[3 * r + 1]);   // :461-464
-        // (x = b z + a with a AND b in SGPRs costs two v_mov_b32 per evaluation — see MathRegs — but pinning the three a's in
-        //  VGPRs as well takes the kernel past 80 VGPRs: 5 resident waves per SIMD instead of 6, which at 1e6 paths leaves
-        //  a lone fourth round, 7.06 -> 7.72 ms; held under 80 it spills.  They stay scalar.  DESIGN.md 5)
-        const double g1 = monthly_gross(P.a1, P.b1, z_eq, tab, M);
-        const double ginf = monthly_gross(P.ainf, P.binf, z_inf, tab, M);
-        const double gprem = monthly_gross(P.aprem, P.bprem, z_prem, tab, M);
+        const int je = 3 * r, ji = 3 * r + 1, jp = 3 * r + 2;
+        const double x_eq = fma_vvs(P.b1 * rad[je >> 1], trig[je], P.a1);
+        const double x_inf = __builtin_fma(P.binf_rho * rad[je >> 1], trig[je], fma_vvs(P.binf_rho_c * rad[ji >> 1], trig[ji], P.ainf));
+        const double x_prem = fma_vvs(P.bprem * rad[jp >> 1], trig[jp], P.aprem);
+        const double g1 = fexp(x_eq, tab, M);
+        const double ginf = fexp(x_inf, tab, M);
+        const double gprem = fexp(x_prem, tab, M);
         stage[(3 * r + 0) * kBlock] = g1;
         stage[(3 * r + 1) * kBlock] = ginf;
         stage[(3 * r + 2) * kBlock] = ginf * gprem;                             // :532

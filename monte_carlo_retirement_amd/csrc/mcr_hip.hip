@@ -698,6 +698,8 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     d->rho = p->equity_inflation_rho;
     const double om = 1.0 - d->rho * d->rho;
     d->rho_c = std::sqrt(om > 0.0 ? om : 0.0);  // :463
+    d->binf_rho = d->binf * d->rho;
+    d->binf_rho_c = d->binf * d->rho_c;
     d->working_months = wm;
     d->retirement_years = p->retirement_years;
     d->total_months = sz.total_months;
