@@ -15,4 +15,4 @@ for _ in range(6):
     ts.append(e0.elapsed_time(e1))
 ms = float(np.median(ts[1:]))
 gb = 8 * n * b.slab.shape[0] / 1e9
-print(f"n={n} rows={b.slab.shape[0]} K3 {ms:.3f} ms  {gb/ms:.3f} TB/s  frac {gb/ms/8:.4f}  fallback {A.last_fallback_rows()}  (cap {os.environ.get('MCR_DBG_CAP','4096')})")
+print(f"n={n} rows={b.slab.shape[0]} K3 {ms:.3f} ms  {gb/ms:.3f} TB/s  frac {gb/ms/8:.4f}  fallback {A.last_fallback_rows()}")
