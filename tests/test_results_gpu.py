@@ -155,3 +155,19 @@ def test_compact_document_on_the_bracketed_quantile_route():
     for key in ("summary", "trajectory", "trajectory_real", "withdrawal_rate", "reference_lines"):
         assert json.dumps(compact[key], allow_nan=True) == json.dumps(full[key], allow_nan=True), key
     assert compact["ruin_histogram"]["failure_count"] == full["ruin_histogram"]["failure_count"]
+
+
+def test_document_preserves_the_exact_fractional_timeline():
+    """The reference's test_api_preserves_exact_fractional_timeline (tests/test_simulation_correctness.py:781-817) on
+    the GPU class + results.build_result: a 13-month working period puts the retirement marker at 13/12 years, not 1.1."""
+    from test_simulator_cpu import _base_config
+
+    config = _base_config(num_simulations_main=2, num_processes=1, retirement_years=1, monthly_expenses=0.0, seed=5)
+    simulator = RetirementMonteCarloSimulator(config)
+    result = R.build_result(config, simulator, required_w_months=13,
+                            search_curve=[{"working_months": 13, "working_years": 1.1, "probability": 100.0}])
+    retirement_year = 13 / 12
+    assert result["trajectory"]["years"] == pytest.approx([0.0, 1.0, retirement_year, retirement_year + 1])
+    assert result["withdrawal_rate"]["years"][0] == pytest.approx(retirement_year)
+    assert result["reference_lines"][0]["year"] == pytest.approx(retirement_year)
+    assert result["summary"]["working_period_is_estimate"] is True
