@@ -146,7 +146,7 @@ def accuracy_10k():
             "source": "tests/golden/metric_10k_config_json.{json,npz} (the reference's own flags on identical shocks)"}
 
 
-def s60_block(torch, dist, world, n_total, reps=3):
+def s60_block(torch, dist, world, n_total, reps=3, grouped=None):
     """North-star shape (BASELINE configs[3]): S60 = config.json with initial_balance=2e6,
     inv1 volatility 0.15, rho=0.3, wm=120 (720-month paths); success counts + 100-bin histogram of the
     successful final balances over `n_total` paths IN TOTAL, sharded by global path range over the ranks
@@ -160,16 +160,17 @@ def s60_block(torch, dist, world, n_total, reps=3):
         cfg = Config(**dict(json.load(fh), initial_balance=2.0e6, inv1_returns_volatility=0.15,
                             equity_inflation_correlation=0.3, seed=12345))
     p = params_from_config(cfg)
+    grouped = world > 1 if grouped is None else grouped
     times, r = [], None
     for _ in range(reps):
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         r = D.run_sharded_histogram(p, 12345, 1, n_total, 120, n_bins=100)
         torch.cuda.synchronize()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if grouped:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         times.append(float(dt.item()))
         del dt
@@ -261,12 +262,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device)
-    if world > 1:
+    # `grouped`: the N > 1 code path (process group, per-step exchange, collectives in the s60 block).  MCR_BENCH_FORCE_GROUP=1
+    # takes it with ONE rank too: the only way to run the RCCL calls of this file on a one-GPU box (tests/test_bench_gpu.py).
+    grouped = world > 1 or os.environ.get("MCR_BENCH_FORCE_GROUP") == "1"
+    if grouped:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(args.backend)
-    comm_dev = torch.device("cuda", device) if (world == 1 or args.backend == "nccl") else torch.device("cpu")
+    comm_dev = torch.device("cuda", device) if (not grouped or args.backend == "nccl") else torch.device("cpu")
 
     with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
         cfg = Config(**dict(json.load(fh), seed=12345))
@@ -298,11 +306,11 @@ def main():
     def step(i):
         # global path index: step-major, then rank (every path of the job is distinct)
         batch.launch(12345, 1, (i * world + rank) * n)
-        if world > 1:
+        if grouped:
             exchange(i)
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -318,23 +326,23 @@ def main():
         ev[i][0].record()
         batch.launch(12345, 1, ((args.warmup + i) * world + rank) * n)
         ev[i][1].record()
-        if world > 1:
+        if grouped:
             exchange(i)
     drain()
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # HIP events on the launch stream
     # local running totals of the timed steps; with N ranks the last exchange holds the job's totals
-    counters = (exch2[(args.steps - 1) & 1] if world > 1 else batch.reduce_vec)[:2].cpu().tolist()
+    counters = (exch2[(args.steps - 1) & 1] if grouped else batch.reduce_vec)[:2].cpu().tolist()
 
     s60 = None
     if not args.no_s60:
         try:
-            s60 = s60_block(torch, dist, world, args.s60_paths)
+            s60 = s60_block(torch, dist, world, args.s60_paths, grouped=grouped)
         except Exception as exc:  # never lose the headline line to the auxiliary block
             s60 = {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -366,7 +374,7 @@ def main():
                 "paths_per_gpu_per_step": n,
                 "rng": "Philox4x32-10 + Box-Muller, counter=(path,month,stream), key=seed",
                 "parallelism": f"path-range sharding x{world}" + (
-                    f" + 1 all-reduce(sum) of the {exch.numel()}-word counter/bin vector per step ({args.backend}), overlapped with the next step's compute" if world > 1 else ""),
+                    f" + 1 all-reduce(sum) of the {exch.numel()}-word counter/bin vector per step ({args.backend}), overlapped with the next step's compute" if grouped else ""),
             },
             "roofline": {
                 "kernel": "mcr::path_kernel<0, 0, true, false>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
@@ -403,7 +411,7 @@ def main():
                           f"(oracle/mcr_oracle.c, scalar fp64, {secs:.1f} s wall)",
             }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -53,3 +53,48 @@ def test_bench_single_gpu_line_has_the_contract_keys():
     acc = out["accuracy_10k"]      # BASELINE's "success-prob abs error vs CPU ref, 10k-path config"
     assert "error" not in acc, acc
     assert acc["abs_error"] <= 1e-4 and acc["flipped_success_flags"] == 0
+
+
+def test_bench_group_code_path_over_rccl_with_one_rank():
+    """The N > 1 code path of bench.py — process group with device_id, asynchronous per-step all-reduce on alternating
+    copies, barrier, max-over-ranks timing, the s60 block's barrier/all-reduce, teardown — with the `nccl` (= RCCL)
+    backend.  One rank is all a one-GPU box can give RCCL, but it is the real library and the real calls."""
+    n, steps = 200_000, 4
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MCR_BENCH_FORCE_GROUP="1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", str(steps), "--warmup", "2", "--paths", str(n),
+                        "--s60-paths", "300001", "--no-aux", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["paths_counted"] == steps * n            # the last exchange holds the totals
+    assert "all-reduce(sum)" in out["config"]["parallelism"] and "nccl" in out["config"]["parallelism"]
+    assert "error" not in out["s60"] and out["s60"]["paths_counted"] == 300001
+
+
+def test_library_collectives_over_rccl_with_one_rank(tmp_path):
+    """distributed.py's wrappers (sum / min-max all-reduce, broadcast) and the sharded bracketed quantile route — whose
+    reduce callback crosses the C boundary and all-reduces slices of the scratch block — on the `nccl` backend."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from monte_carlo_retirement_amd import aggregation as A, distributed as D\n"
+        "t = torch.arange(10, dtype=torch.int64, device='cuda'); D.all_reduce_sum_(t); assert t.tolist() == list(range(10))\n"
+        "m = torch.tensor([3.5, -2.0], dtype=torch.float64, device='cuda'); D.all_reduce_minmax_(m); assert m.tolist() == [3.5, -2.0]\n"
+        "b = torch.tensor([2**62 + 5], dtype=torch.int64, device='cuda'); dist.broadcast(b, src=0); assert int(b.item()) == 2**62 + 5\n"
+        "w = dist.all_reduce(torch.ones(4, dtype=torch.int64, device='cuda'), async_op=True); w.wait()\n"
+        "n = 1 << 22\n"
+        "rng = np.random.default_rng(4)\n"
+        "rows = np.stack([rng.lognormal(12, 1, n), np.where(rng.random(n) < 0.3, np.nan, rng.normal(0, 5, n)), np.full(n, 7.0)])\n"
+        "dev = torch.as_tensor(rows, device='cuda')\n"
+        "got, counts = A.row_quantiles(dev, n, A.TRAJECTORY_QUANTILES, reduce_counts=D.all_reduce_sum_, n_total=n)\n"
+        "assert A.last_fallback_rows() == 0, A.last_fallback_rows()      # the sharded BRACKETED route ran (callback -> RCCL)\n"
+        "plain, pc = A.row_quantiles(dev, n, A.TRAJECTORY_QUANTILES)\n"
+        "assert np.array_equal(got, plain, equal_nan=True) and counts.tolist() == pc.tolist()\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
