@@ -63,8 +63,9 @@ constexpr unsigned long long kNanBits = 0x7ff8000000000000ull;
 __device__ __forceinline__ unsigned long long f64_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) { *reinterpret_cast<unsigned long long*>(p) = bits; }
 
-// __launch_bounds__(256, 4): the kernel saturates the fp64 VALU with 4 waves per SIMD (measured by capping
-// residency), so the register allocator may use up to 128 VGPRs instead of spilling scalars.  The count-only Philox
+// __launch_bounds__(256, 4) for the variants with per-path outputs: up to 128 VGPRs rather than spills (they carry the
+// output state on top of the path state).  Residency is not free, though: the trimmed count-only kernel loses 4.4 % on
+// large batches at 4 instead of 6 workgroups per CU (measured with a larger LDS footprint).  The count-only Philox
 // variants are held to 6 waves per SIMD (<= 80 VGPRs): the BASELINE workload of 1e6 paths is 15.26 waves per SIMD, and
 // with 5 resident waves that is 5 + 5 + 5 + a lone fourth round (+9 %); the annual-tax variant sat at 81.
 // INJ = true: shocks come from io.injected (the parity hook) instead of the RNG; only instantiated with MODE 2
