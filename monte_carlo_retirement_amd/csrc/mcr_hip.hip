@@ -63,9 +63,11 @@ constexpr unsigned long long kNanBits = 0x7ff8000000000000ull;
 __device__ __forceinline__ unsigned long long f64_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) { *reinterpret_cast<unsigned long long*>(p) = bits; }
 
-// __launch_bounds__(256, 4) for the variants with per-path outputs: up to 128 VGPRs rather than spills (they carry the
-// output state on top of the path state).  Residency is not free, though: the trimmed count-only kernel loses 4.4 % on
-// large batches at 4 instead of 6 workgroups per CU (measured with a larger LDS footprint).  The count-only Philox
+// Resident waves per SIMD are worth more than a few spilled registers: the trimmed count-only kernel loses 4.4 % on
+// large batches at 4 instead of 6 workgroups per CU (measured with a larger LDS footprint), and the Philox
+// variants with per-path outputs gain 4.5 % (summary) / 3 % (trajectories) at 5 waves (<= 96 VGPRs, 4-10 of them
+// spilled) over 4 (up to 128); at 6 the summary variant spills too much and gives that back.  The NumPy-stream and
+// injection variants keep 4 (they need 107-128).  The count-only Philox
 // variants are held to 6 waves per SIMD (<= 80 VGPRs): the BASELINE workload of 1e6 paths is 15.26 waves per SIMD, and
 // with 5 resident waves that is 5 + 5 + 5 + a lone fourth round (+9 %); the annual-tax variant sat at 81.
 // INJ = true: shocks come from io.injected (the parity hook) instead of the RNG; only instantiated with MODE 2
@@ -78,7 +80,7 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 #define MCR_K1_WAVES_ATTR
 #endif
 template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0>
-__global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
+__global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
     // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
