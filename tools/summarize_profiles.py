@@ -38,12 +38,13 @@ def label(kernel_name: str):
 
 def main(src: str, dst: str) -> None:
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    # (the newest one: a re-used output directory may still hold an older collection's files)
+    stats = max(glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_default.json"))
     per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in ("pmc_sq", "pmc_mix", "pmc_fetch", "pmc_write"):
-        f = glob.glob(os.path.join(src, d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        f = max(glob.glob(os.path.join(src, d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
         for r in csv.DictReader(open(f)):
             short = label(r["Kernel_Name"])
             if short:
