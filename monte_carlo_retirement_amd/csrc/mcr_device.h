@@ -183,7 +183,7 @@ __device__ __forceinline__ double monthly_gross(double a, double b, double z, co
 // (g1, g_inflation, g2 = g_inflation * g_premium; :522-532) in the lane's own LDS column:
 // `stage[j * kBlock]`, j = 3 * (row & 1) + {0, 1, 2} (12 KB per workgroup).  The six pairs of a HALF are
 // independent straight-line work (lots of instruction-level parallelism next to the serial month bodies of
-// the other waves).  Every value is produced by the same expressions as shock_row_seq + monthly_gross.
+// the other waves).  The normals are shock_row_seq's; the log-returns are associated on their parts (below).
 struct PairCarry { uint32_t w2, w3; };
 template <int HALF>
 __device__ __forceinline__ void growth_rows2(const DevParams& P, const MathRegs& M, uint64_t seed, uint32_t stream_id, uint64_t path,
