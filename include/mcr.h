@@ -285,7 +285,7 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
  * unsupported shape.
  *
  * mcr_row_quantiles picks the route by row length.  Short rows: the exact radix select (8 digit passes,
- * 4 of them over the slab), fully asynchronous.  Rows of >= 2^21 entries, SIX launches: the first 4096 entries of
+ * 4 of them over the slab), fully asynchronous.  Rows of >= 2^14 entries, SIX launches: the first 4096 entries of
  * every row are sorted in LDS (coarse brackets); a counting pass over a sample (the first n/32 entries) and a small
  * per-row kernel turn them into fine brackets; ONE pass over the slab counts the keys around the brackets (with
  * sub-histograms inside them) and compacts the few % inside; two per-row kernels locate every target in one

@@ -1532,12 +1532,14 @@ static int rq_radix_select(const double* rows, int64_t row_stride, int32_t n_row
     return rc;
 }
 
-// Rows at least this long take the bracketed single pass (below it the extra launches cost more than the
-// three streaming passes they save).  MCR_RQ_BRACKET_MIN_N overrides it (tests force either route).
+// Rows at least this long take the bracketed single pass.  Measured on 136 rows (tools/k3_time.py, either route forced):
+// the six-launch route wins from the smallest row it accepts — 8 192 entries 0.21 vs 0.24 ms, 131 072: 0.28 vs 0.36,
+// 10^6: 0.48 vs 1.11, 2 10^6: 0.71 vs 2.01 — (round 1's 45-launch version needed 2^21 entries to pay).  16 384 keeps a
+// margin for rows whose brackets fail and take both routes.  MCR_RQ_BRACKET_MIN_N overrides it (tests force either route).
 static int64_t rq_bracket_min_n() {
     const char* e = std::getenv("MCR_RQ_BRACKET_MIN_N");
     if (e && *e) return (int64_t)std::strtoll(e, nullptr, 10);
-    return (int64_t)1 << 21;
+    return (int64_t)1 << 14;
 }
 
 static thread_local int g_last_fallback_rows = -1;

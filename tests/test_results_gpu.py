@@ -139,7 +139,7 @@ def test_compact_document_at_a_million_paths():
 
 
 def test_compact_document_on_the_bracketed_quantile_route():
-    """2.2 million paths (rows above the 2^21 threshold): the summary statistics and the bands of the compact document
+    """2.2 million paths (long rows, the bracketed quantile route): the summary statistics and the bands of the compact document
     come from the sample-bracketed single-pass select, and still equal pandas on the per-path frame exactly."""
     case = CASES[1]                                   # the failing scenario: NaN-masked cohorts are non-trivial
     n = 2_200_000
