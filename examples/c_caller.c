@@ -5,7 +5,7 @@
  *       -Lmonte_carlo_retirement_amd/csrc -lmcr_hip -Wl,-rpath,$PWD/monte_carlo_retirement_amd/csrc -lm
  *   ./c_caller [n_paths] [working_months] [seed]
  *
- * prints one line: `paths=<n> success=<count> probability=<p> devices=<d>`.
+ * prints `paths=<n> success=<count> probability=<p> devices=<d>` and `hist=<10 comma-separated bin counts>`.
  * The lognormal parameters follow arithmetic_to_log_params (backend/simulation.py:14-29), as __init__ derives them
  * (:156-170). */
 #include <math.h>
@@ -82,6 +82,16 @@ int main(int argc, char** argv) {
     memset(&out, 0, sizeof out); /* every per-path pointer NULL: the success-count-only kernel */
     out.path_stride = (int64_t)n_paths;
     out.counters = counters;
+    /* final balances of the successful paths on 10 log-spaced bins from 1e5 to 1e10 dollars, binned inside the path
+     * kernel (np.histogram(final[success], bins=edges); backend/plotting.py:44-59 charts this cohort) */
+    enum { N_BINS = 10 };
+    double edges[N_BINS + 1];
+    uint64_t bins[N_BINS];
+    for (int k = 0; k <= N_BINS; ++k) edges[k] = 1e5 * pow(10.0, 0.5 * k);
+    memset(bins, 0, sizeof bins);
+    out.hist_edges = edges;
+    out.hist_bins = bins;
+    out.hist_n_bins = N_BINS;
 
     const int rc = mcr_run_batch_multi_host_rng(&p, &rng, /*stream_id=*/1u, /*path_begin=*/0u, n_paths, working_months,
                                                 /*injected_shocks=*/NULL, &out, /*devices=*/NULL, /*n_devices=*/0);
@@ -91,5 +101,7 @@ int main(int argc, char** argv) {
     }
     printf("paths=%llu success=%llu probability=%.6f devices=%d\n", (unsigned long long)counters[MCR_CTR_PATHS],
            (unsigned long long)counters[MCR_CTR_SUCCESS], (double)counters[MCR_CTR_SUCCESS] / (double)counters[MCR_CTR_PATHS], devices);
+    printf("hist=");
+    for (int k = 0; k < N_BINS; ++k) printf("%llu%s", (unsigned long long)bins[k], k + 1 < N_BINS ? "," : "\n");
     return 0;
 }

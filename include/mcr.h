@@ -24,9 +24,10 @@
 extern "C" {
 #endif
 
-#define MCR_ABI_VERSION 5
+#define MCR_ABI_VERSION 6
 #define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
 #define MCR_MAX_PROBE_CANDIDATES 32 /* candidates of one mcr_probe_months_rng call that can share their accumulation sweep */
+#define MCR_MAX_HIST_BINS 4096  /* bins of the in-kernel final-balance histogram (mcr_outputs.hist_bins) */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
 #define MCR_SMALL_EPSILON 1e-6  /* backend/constants.py:3 (absolute dollar threshold) */
 
@@ -146,6 +147,21 @@ typedef struct mcr_outputs {
     uint64_t* ruin_year_bins;                 /* [ry+2] [0]=pre-retirement tax failure (YearsToRuin 0.0,
                                                  simulation.py:628-629); [1+y]=failed in retirement year y;
                                                  [ry+1]=failed at the terminal tax settlement (:894-896) */
+    /* In-kernel histogram of "Final Balance" over the successful cohort (the CLI's chart, backend/plotting.py:44-59) on
+     * CALLER-SUPPLIED bin edges: hist_bins[k] += #{successful paths: hist_edges[k] <= Final Balance < hist_edges[k+1]}, the
+     * last bin closed on the right, values outside [hist_edges[0], hist_edges[hist_n_bins]] dropped — exactly
+     * np.histogram(final_balance[success], bins=hist_edges); with hist_edges = np.linspace(lo, hi, n + 1) that is also
+     * np.histogram(..., bins=n, range=(lo, hi)), and any other monotone spacing (np.geomspace for log-spaced bins) works
+     * the same way.  Every lane bins its own path at the end of the horizon (binary search over the edges, LDS-privatised
+     * bins, one global atomic per non-empty bin per workgroup): no per-path output, no second kernel, and the bins sit in
+     * the same accumulated integer block as the counters — a multi-GPU caller sums everything with ONE all-reduce.
+     * hist_edges: [hist_n_bins + 1] ascending finite doubles (DEVICE pointer for mcr_run_batch*, HOST for *_host*);
+     * hist_n_bins in 1..MCR_MAX_HIST_BINS (above 512 bins the LDS footprint costs one resident workgroup per CU);
+     * hist_bins == NULL or hist_n_bins == 0: not requested. */
+    const double* hist_edges;
+    uint64_t* hist_bins;                      /* [hist_n_bins], accumulated into like the counters */
+    int32_t hist_n_bins;
+    int32_t hist_reserved;                    /* 0 */
 } mcr_outputs;
 
 /* ---- library / device ------------------------------------------------------------ */
@@ -154,6 +170,11 @@ int mcr_abi_version(void);
 int mcr_device_count(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* mcr_last_error(void);
+
+/* Frees the library's idle cached device resources on `device` (< 0: every device): the leased-context pool of the
+ * *_host entry points (streams + scratch blocks, see mcr_run_batch_host) and the side streams of mcr_probe_months_rng.
+ * Contexts that are in use by concurrent calls are untouched.  Safe to call at any time from any thread. */
+int mcr_release_cached(int device);
 
 /* ---- host-side derivations (no device needed) -------------------------------------- */
 /* Shapes for (params, working_months).  Returns MCR_ERR_INVALID_ARG for working_months<0,
@@ -191,11 +212,13 @@ int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id,
                   int device, void* hip_stream);
 
 /* Same, with HOST buffers in `out` / `injected_shocks` (the entry point for non-torch callers, e.g. a ctypes
- * binding inside the reference's run_monte_carlo_simulations, simulation.py:952-1010): device buffers are carved
- * from a scratch block cached per (calling thread, device), uploads / kernel / downloads run on that thread's
- * private non-blocking stream, and the call returns after ONE synchronisation of that stream — concurrent calls
- * from several host threads (the reference's server runs requests on executor threads, server.py:309,405)
- * overlap on the GPU.  Scratch blocks up to 256 MiB stay cached between calls; larger ones are freed on return.
+ * binding inside the reference's run_monte_carlo_simulations, simulation.py:952-1010): the call LEASES a context
+ * (a private non-blocking stream + a scratch block its device buffers are carved from) out of a process-wide pool
+ * keyed by device, runs uploads / kernel / downloads on that stream, returns after ONE synchronisation of it and
+ * hands the context back — concurrent calls from several host threads (the reference's server runs requests on
+ * executor threads, server.py:309,405) overlap on the GPU, and short-lived caller threads leave nothing behind.
+ * Retention: at most 4 idle contexts per device stay cached, each with a block of at most 256 MiB (larger blocks are
+ * freed on return); mcr_release_cached() frees them on demand.
  * device: a HIP device ordinal, or MCR_DEVICE_ALL = shard the path range over every visible device (below). */
 #define MCR_DEVICE_ALL (-2)
 int mcr_run_batch_host(const mcr_params* p, uint64_t seed, uint32_t stream_id,

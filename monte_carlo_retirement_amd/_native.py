@@ -12,7 +12,7 @@ import os
 import threading
 from typing import Optional
 
-MCR_ABI_VERSION = 5
+MCR_ABI_VERSION = 6
 MCR_MAX_STREAMS = 16
 MCR_N_COUNTERS = 2
 MCR_N_STAT_ROWS = 4
@@ -24,6 +24,7 @@ MCR_RNG_PHILOX = 0
 MCR_RNG_NUMPY = 1
 MCR_MAX_ENTROPY_WORDS = 8
 MCR_DEVICE_ALL = -2
+MCR_MAX_HIST_BINS = 4096
 
 MCR_HELPER_WITHDRAW = 0
 MCR_HELPER_NLV = 1
@@ -172,6 +173,10 @@ class McrOutputs(C.Structure):
         ("counters", C.c_void_p),
         ("wr_obs_counts", C.c_void_p),
         ("ruin_year_bins", C.c_void_p),
+        ("hist_edges", C.c_void_p),
+        ("hist_bins", C.c_void_p),
+        ("hist_n_bins", C.c_int32),
+        ("hist_reserved", C.c_int32),
     ]
 
 
@@ -191,6 +196,7 @@ ABI_SYMBOLS = (
     "mcr_probe_months_rng",
     "mcr_run_batch_multi_host_rng",
     "mcr_validate_params",
+    "mcr_release_cached",
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
@@ -263,6 +269,8 @@ def _declare(lib: C.CDLL) -> None:
     ]
     lib.mcr_validate_params.restype = C.c_int
     lib.mcr_validate_params.argtypes = [P(McrParams)]
+    lib.mcr_release_cached.restype = C.c_int
+    lib.mcr_release_cached.argtypes = [C.c_int]
     lib.mcr_draw_shocks_host_rng.restype = C.c_int
     lib.mcr_draw_shocks_host_rng.argtypes = [
         P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_double, C.c_void_p, C.c_int,

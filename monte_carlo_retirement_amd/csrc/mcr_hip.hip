@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -106,10 +107,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     double* stage = stage_s + (kStaged ? threadIdx.x : 0);
     double* lock_lds = reinterpret_cast<double*>(smem_raw + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0));
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
-    // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram
+    // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram; then the
+    // [hist_n_bins] final-balance histogram of the workgroup (mcr_outputs.hist_bins), when requested
     const int ry = P.retirement_years;
     const int n_blk = 1 + (ry + 2) + (ry + 1);
-    for (int k = threadIdx.x; k < n_blk; k += kBlock) blk[k] = 0u;
+    const int n_hist = (PHASE == 0 && io.out.hist_bins != nullptr) ? io.out.hist_n_bins : 0;
+    for (int k = threadIdx.x; k < n_blk + n_hist; k += kBlock) blk[k] = 0u;
     __syncthreads();
 
     const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -383,6 +386,20 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
         if (ruin_bin >= 0) atomicAdd(&blk[1 + ruin_bin], 1u);
         atomicAdd(&blk[1 + (ry + 2) + done_years], 1u);
     }
+    // "Final Balance" of the successful cohort on the caller's bin edges (plotting.py:44-59; np.histogram(x, bins=edges):
+    // bin k = [e_k, e_k+1), the last one closed, values outside the edges dropped).  Once per path, after 10^2..10^3
+    // months of arithmetic: a per-lane binary search straight over the (L2-resident) edge array costs nothing measurable.
+    if (PHASE == 0 && n_hist > 0 && valid && succeeded) {
+        const double* __restrict__ e = io.out.hist_edges;
+        if (final_balance >= e[0] && final_balance <= e[n_hist]) {
+            int lo = 0, hi = n_hist;             // e[lo] <= x and (hi == n_hist or x < e[hi])
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (e[mid] <= final_balance) lo = mid; else hi = mid;
+            }
+            atomicAdd(&blk[n_blk + lo], 1u);
+        }
+    }
     __syncthreads();
     uint64_t* ctr = io.out.counters ? io.out.counters + (PHASE == 2 ? (size_t)io.cand_out[blockIdx.y] * MCR_N_COUNTERS : 0) : nullptr;
     if (threadIdx.x == 0 && ctr) {
@@ -404,6 +421,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
                 atomicAdd((unsigned long long*)&io.out.wr_obs_counts[y], (unsigned long long)c);
         }
     }
+    for (int k = threadIdx.x; k < n_hist; k += kBlock)   // one global atomic per non-empty bin per workgroup
+        if (blk[n_blk + k]) atomicAdd((unsigned long long*)&io.out.hist_bins[k], (unsigned long long)blk[n_blk + k]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,15 +589,45 @@ int use_device(int device) {
     return MCR_OK;
 }
 
-// ---- per (thread, device) context of the host-buffer entry points (mcr_host.h) ----
-HostCtx* host_ctx(int device) {
-    static thread_local std::vector<HostCtx*> pool;
-    for (HostCtx* c : pool) if (c->device == device) return c;
+// ---- leased contexts of the host-buffer entry points (mcr_host.h): a process-wide pool keyed by device ----
+static std::mutex g_pool_mu;
+static std::vector<HostCtx*> g_idle_ctx;   // idle contexts, most recently used last
+
+static void host_ctx_destroy(HostCtx* c) {   // (the caller has set the device)
+    if (c->block) (void)hipFree(c->block);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+HostCtx* host_ctx_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (size_t i = g_idle_ctx.size(); i-- > 0;)
+            if (g_idle_ctx[i]->device == device) {
+                HostCtx* c = g_idle_ctx[i];
+                g_idle_ctx.erase(g_idle_ctx.begin() + (long)i);
+                return c;
+            }
+    }
     HostCtx* c = new HostCtx{device, nullptr, nullptr, 0};
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hip_fail(e, "hipStreamCreate (host context)"); delete c; return nullptr; }
-    pool.push_back(c);
     return c;
+}
+
+void host_ctx_release(HostCtx* c) {
+    if (c->capacity > kHostCtxKeepBytes) { (void)hipFree(c->block); c->block = nullptr; c->capacity = 0; }
+    HostCtx* surplus = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_idle_ctx.push_back(c);
+        int same = 0;
+        for (HostCtx* o : g_idle_ctx) same += o->device == c->device;
+        if (same > kHostCtxIdlePerDevice)   // drop the least recently used idle context of this device
+            for (size_t i = 0; i < g_idle_ctx.size(); ++i)
+                if (g_idle_ctx[i]->device == c->device) { surplus = g_idle_ctx[i]; g_idle_ctx.erase(g_idle_ctx.begin() + (long)i); break; }
+    }
+    if (surplus) host_ctx_destroy(surplus);   // same device as the call that is ending: it is still current
 }
 
 hipError_t host_ctx_reserve(HostCtx* c, size_t bytes) {
@@ -587,10 +636,6 @@ hipError_t host_ctx_reserve(HostCtx* c, size_t bytes) {
     hipError_t e = hipMalloc(&c->block, bytes);
     if (e == hipSuccess) c->capacity = bytes; else c->block = nullptr;
     return e;
-}
-
-void host_ctx_release_large(HostCtx* c) {
-    if (c->capacity > kHostCtxKeepBytes) { (void)hipFree(c->block); c->block = nullptr; c->capacity = 0; }
 }
 
 // Preconditions of the path kernel (its STRICT = false forms drop clamps that are no-ops only for rates and
@@ -731,11 +776,11 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
 }
 
 constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)kStageDoubles * sizeof(double);   // (upper bound over the variants)
-static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng) {
+static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng, int n_hist_bins = 0) {
     // the dynamic part only: the math tables and the stage of growth factors are static LDS of the kernel
     return (numpy_rng ? (size_t)kZigLdsBytes : (size_t)0) +
            (size_t)d.n_lock_slots * kBlock * sizeof(double) +
-           (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1)) * sizeof(unsigned int);
+           (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1) + n_hist_bins) * sizeof(unsigned int);
 }
 
 static int check_rng(const mcr_rng* rng) {
@@ -784,8 +829,13 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
         return MCR_ERR_INVALID_ARG;
     }
     const bool np_rng = rng->kind == MCR_RNG_NUMPY;
-    const size_t lds = path_kernel_lds_bytes(d, np_rng);
-    if (lds + kPathKernelStaticLds > 64 * 1024) { set_error("too many non-indexed streams / retirement years for LDS"); return MCR_ERR_UNSUPPORTED; }
+    if (io.out.hist_bins == nullptr || io.out.hist_n_bins == 0) { io.out.hist_bins = nullptr; io.out.hist_edges = nullptr; io.out.hist_n_bins = 0; }
+    if (io.out.hist_bins && (io.out.hist_n_bins < 0 || io.out.hist_n_bins > MCR_MAX_HIST_BINS || !io.out.hist_edges)) {
+        set_error("hist_bins requested with hist_n_bins = %d (1..%d) / hist_edges = %p", io.out.hist_n_bins, MCR_MAX_HIST_BINS, (const void*)io.out.hist_edges);
+        return MCR_ERR_INVALID_ARG;
+    }
+    const size_t lds = path_kernel_lds_bytes(d, np_rng, io.out.hist_n_bins);
+    if (lds + kPathKernelStaticLds > 64 * 1024) { set_error("too many non-indexed streams / retirement years / histogram bins for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
     // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
@@ -857,27 +907,69 @@ int mcr_run_batch_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_i
                         (hipStream_t)hip_stream);
 }
 
-// Fork/join helper for mcr_probe_months_rng: a few non-blocking side streams per (thread, device), created on
-// first use and kept for the life of the process (destroying HIP objects from thread-exit hooks is not safe).
+// Fork/join helper for mcr_probe_months_rng: a few non-blocking side streams, leased from a process-wide pool keyed by
+// device for the duration of ONE call's enqueue (like HostCtx).  A lease only has to cover the host-side enqueue: the
+// side streams are in-order, and a stream that waits on an event waits for the record that preceded the wait call, so
+// the next lessee's records cannot disturb work that is still running.
 namespace {
 constexpr int kProbeStreams = 8;
+constexpr int kProbeForkIdlePerDevice = 2;
 struct ProbeFork {
+    int device;
     hipStream_t side[kProbeStreams];
     hipEvent_t done[kProbeStreams];
     hipEvent_t fork;
 };
-ProbeFork* probe_fork(int device) {
-    static thread_local std::vector<std::pair<int, ProbeFork*>> pools;
-    for (auto& pr : pools) if (pr.first == device) return pr.second;
+std::vector<ProbeFork*> g_idle_fork;   // guarded by g_pool_mu
+
+void probe_fork_destroy(ProbeFork* f) {   // pending work on a destroyed stream still completes (stream-ordered release)
+    for (int i = 0; i < kProbeStreams; ++i) {
+        if (f->done[i]) (void)hipEventDestroy(f->done[i]);
+        if (f->side[i]) (void)hipStreamDestroy(f->side[i]);
+    }
+    if (f->fork) (void)hipEventDestroy(f->fork);
+    delete f;
+}
+ProbeFork* probe_fork_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (size_t i = g_idle_fork.size(); i-- > 0;)
+            if (g_idle_fork[i]->device == device) {
+                ProbeFork* f = g_idle_fork[i];
+                g_idle_fork.erase(g_idle_fork.begin() + (long)i);
+                return f;
+            }
+    }
     ProbeFork* f = new ProbeFork();
+    std::memset(f, 0, sizeof(*f));
+    f->device = device;
     bool ok = hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < kProbeStreams; ++i)
         ok = hipStreamCreateWithFlags(&f->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&f->done[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); delete f; return nullptr; }   // partial objects leak: out-of-resources path only
-    pools.emplace_back(device, f);
+    if (!ok) { (void)hipGetLastError(); probe_fork_destroy(f); return nullptr; }
     return f;
 }
+void probe_fork_release(ProbeFork* f) {
+    ProbeFork* surplus = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_idle_fork.push_back(f);
+        int same = 0;
+        for (ProbeFork* o : g_idle_fork) same += o->device == f->device;
+        if (same > kProbeForkIdlePerDevice)
+            for (size_t i = 0; i < g_idle_fork.size(); ++i)
+                if (g_idle_fork[i]->device == f->device) { surplus = g_idle_fork[i]; g_idle_fork.erase(g_idle_fork.begin() + (long)i); break; }
+    }
+    if (surplus) probe_fork_destroy(surplus);
+}
+struct ProbeForkLease {
+    explicit ProbeForkLease(int device) : f(probe_fork_acquire(device)) {}
+    ProbeForkLease(const ProbeForkLease&) = delete;
+    ProbeForkLease& operator=(const ProbeForkLease&) = delete;
+    ~ProbeForkLease() { if (f) probe_fork_release(f); }
+    ProbeFork* f;
+};
 }  // namespace
 
 // Several candidates over the same paths, Philox stream: ONE accumulation sweep to the largest candidate that stores the
@@ -965,7 +1057,8 @@ int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t strea
         const int prc = probe_shared_prefix(p, rng, stream_id, path_begin, n_paths, working_months, n_candidates, counts, main);
         if (prc != MCR_ERR_UNSUPPORTED) return prc;     // (unsupported shape / allocation refused: one launch per candidate below)
     }
-    ProbeFork* f = probe_fork(device);
+    ProbeForkLease fork_lease(device);
+    ProbeFork* f = fork_lease.f;
     if (!f) { set_error("could not create probe streams"); return MCR_ERR_HIP; }
     const int used = n_candidates < kProbeStreams ? n_candidates : kProbeStreams;
     if ((e = hipEventRecord(f->fork, main)) != hipSuccess) return hip_fail(e, "probe fork");
@@ -1044,13 +1137,26 @@ static int run_batch_host_on(int device, const mcr_params* p, const mcr_rng* rng
     plan((void**)&d.counters, out->counters, 1, MCR_N_COUNTERS * sizeof(uint64_t), 0, 0, true, true);
     plan((void**)&d.wr_obs_counts, out->wr_obs_counts, 1, (size_t)sz.retirement_years * sizeof(uint64_t), 0, 0, true, true);
     plan((void**)&d.ruin_year_bins, out->ruin_year_bins, 1, (size_t)sz.ruin_bins * sizeof(uint64_t), 0, 0, true, true);
+    if (out->hist_bins && out->hist_n_bins != 0) {   // in-kernel final-balance histogram on the caller's edges
+        const int nb = out->hist_n_bins;
+        if (nb < 0 || nb > MCR_MAX_HIST_BINS || !out->hist_edges) { set_error("hist_bins requested with hist_n_bins = %d (1..%d) / null hist_edges", nb, MCR_MAX_HIST_BINS); return MCR_ERR_INVALID_ARG; }
+        for (int k = 0; k <= nb; ++k)   // host pointer: the edges can be checked here (np.histogram: "bins must increase monotonically")
+            if (!std::isfinite(out->hist_edges[k]) || (k > 0 && out->hist_edges[k] < out->hist_edges[k - 1])) {
+                set_error("hist_edges[%d] = %g: edges must be finite and ascending", k, out->hist_edges[k]);
+                return MCR_ERR_INVALID_ARG;
+            }
+        d.hist_n_bins = nb;
+        plan((void**)&d.hist_edges, out->hist_edges, 1, (size_t)(nb + 1) * sizeof(double), 0, 0, true, false);
+        plan((void**)&d.hist_bins, out->hist_bins, 1, (size_t)nb * sizeof(uint64_t), 0, 0, true, true);
+    }
     double* d_inj = nullptr;
     plan((void**)&d_inj, injected_shocks, 1, n * (size_t)sz.shock_rows * 3 * sizeof(double), 0, 0, true, false);
     mcr_rng rng = *rng_in;
     uint32_t* d_seeds = nullptr;   // explicit per-path seeds: upload
     plan((void**)&d_seeds, rng.path_seeds, 1, n * sizeof(uint32_t), 0, 0, true, false);
 
-    HostCtx* ctx = host_ctx(device);
+    HostCtxLease lease(device);
+    HostCtx* ctx = lease.ctx;
     if (!ctx) return MCR_ERR_HIP;
     hipError_t e = host_ctx_reserve(ctx, total);
     if (e != hipSuccess) return hip_fail(e, "device allocation (host-buffer batch)");
@@ -1068,8 +1174,7 @@ static int run_batch_host_on(int device, const mcr_params* p, const mcr_rng* rng
             else e = hipMemcpy2DAsync(b.host, b.host_pitch, *b.dev, b.dev_pitch, b.row_bytes, b.rows, hipMemcpyDeviceToHost, ctx->stream);
         }
     }
-    const hipError_t es = hipStreamSynchronize(ctx->stream);   // this thread's stream only
-    host_ctx_release_large(ctx);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);   // this call's stream only
     if (rc != MCR_OK) return rc;
     if (e != hipSuccess) return hip_fail(e, "download");
     if (es != hipSuccess) return hip_fail(es, "path_kernel execution");
@@ -1101,7 +1206,7 @@ static int run_batch_host_multi(const int32_t* devices, int32_t n_devices, const
     struct Shard {
         int rc = MCR_OK;
         char err[512] = "";
-        std::vector<uint64_t> counters, wr, ruin;
+        std::vector<uint64_t> counters, wr, ruin, hist;
     };
     std::vector<Shard> shards(W);
     std::vector<std::thread> threads;
@@ -1113,6 +1218,7 @@ static int run_batch_host_multi(const int32_t* devices, int32_t n_devices, const
         S.counters.assign(MCR_N_COUNTERS, 0);
         S.wr.assign((size_t)sz.retirement_years, 0);
         S.ruin.assign((size_t)sz.ruin_bins, 0);
+        if (out->hist_bins && out->hist_n_bins > 0) S.hist.assign((size_t)out->hist_n_bins, 0);
         threads.emplace_back([&, w, begin, count]() {
             Shard& T = shards[w];
             mcr_outputs o = *out;    // host pointers of this shard's columns
@@ -1125,6 +1231,7 @@ static int run_batch_host_multi(const int32_t* devices, int32_t n_devices, const
             o.counters = out->counters ? T.counters.data() : nullptr;
             o.wr_obs_counts = out->wr_obs_counts ? T.wr.data() : nullptr;
             o.ruin_year_bins = out->ruin_year_bins ? T.ruin.data() : nullptr;
+            o.hist_bins = T.hist.empty() ? nullptr : T.hist.data();
             mcr_rng r = *rng_in;
             if (r.path_seeds) r.path_seeds += begin;
             const double* inj = injected_shocks ? injected_shocks + (size_t)begin * (size_t)sz.shock_rows * 3u : nullptr;
@@ -1140,6 +1247,7 @@ static int run_batch_host_multi(const int32_t* devices, int32_t n_devices, const
         if (out->counters) for (int k = 0; k < MCR_N_COUNTERS; ++k) out->counters[k] += S.counters[k];
         if (out->wr_obs_counts) for (int k = 0; k < sz.retirement_years; ++k) out->wr_obs_counts[k] += S.wr[k];
         if (out->ruin_year_bins) for (int k = 0; k < sz.ruin_bins; ++k) out->ruin_year_bins[k] += S.ruin[k];
+        for (size_t k = 0; k < S.hist.size(); ++k) out->hist_bins[k] += S.hist[k];
     }
     return MCR_OK;
 }
@@ -1159,6 +1267,30 @@ int mcr_run_batch_multi_host_rng(const mcr_params* p, const mcr_rng* rng, uint32
 }
 
 int mcr_validate_params(const mcr_params* p) { return validate_params(p); }
+
+int mcr_release_cached(int device) {
+    std::vector<HostCtx*> ctxs;
+    std::vector<ProbeFork*> forks;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (size_t i = g_idle_ctx.size(); i-- > 0;)
+            if (device < 0 || g_idle_ctx[i]->device == device) { ctxs.push_back(g_idle_ctx[i]); g_idle_ctx.erase(g_idle_ctx.begin() + (long)i); }
+        for (size_t i = g_idle_fork.size(); i-- > 0;)
+            if (device < 0 || g_idle_fork[i]->device == device) { forks.push_back(g_idle_fork[i]); g_idle_fork.erase(g_idle_fork.begin() + (long)i); }
+    }
+    int rc = MCR_OK;
+    for (HostCtx* c : ctxs) {
+        DeviceScope scope(c->device);
+        if (scope.rc != MCR_OK) rc = scope.rc;   // (device gone: drop the bookkeeping anyway)
+        host_ctx_destroy(c);
+    }
+    for (ProbeFork* f : forks) {
+        DeviceScope scope(f->device);
+        if (scope.rc != MCR_OK) rc = scope.rc;
+        probe_fork_destroy(f);
+    }
+    return rc;
+}
 
 int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin, uint64_t n_paths,
                          int32_t n_months, double rho, double* out, int device) {

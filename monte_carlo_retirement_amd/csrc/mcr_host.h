@@ -58,20 +58,33 @@ private:
     std::vector<void*> ptrs_;
 };
 
-// Per (host thread, device) context of the host-buffer entry points (mcr_run_batch_host*): a private
-// NON-BLOCKING stream — concurrent callers (server executor threads) do not serialise on the null stream
-// or on a device-wide synchronise — and one cached scratch block that calls carve their device buffers
-// from.  Blocks up to kHostCtxKeepBytes stay cached between calls; larger ones are released when the call
-// ends.  Contexts live for the life of the process (destroying HIP objects from thread-exit hooks is not safe).
+// Context of one host-buffer call (mcr_run_batch_host*): a private NON-BLOCKING stream — concurrent callers (server
+// executor threads) do not serialise on the null stream or on a device-wide synchronise — and one scratch block that the
+// call carves its device buffers from.  Contexts live in a PROCESS-WIDE pool keyed by device (mutex-guarded): a call
+// leases one for its duration (HostCtxLease) and hands it back, so short-lived caller threads and the per-call shard
+// workers of the multi-device entry reuse the same few contexts instead of leaving one behind each (round 2 kept them in
+// thread-local storage: one stream + up to 256 MiB of HBM leaked per thread that ever called).  At most
+// kHostCtxIdlePerDevice idle contexts per device stay cached, each with a block of at most kHostCtxKeepBytes (larger
+// blocks are freed when the call ends); mcr_release_cached() frees the idle ones on demand.  Concurrency is bounded by
+// the callers: N simultaneous calls use N contexts.
 constexpr size_t kHostCtxKeepBytes = (size_t)256 << 20;
+constexpr int kHostCtxIdlePerDevice = 4;
 struct HostCtx {
     int device;
     hipStream_t stream;
     void* block;
     size_t capacity;
 };
-HostCtx* host_ctx(int device);                       // nullptr + error set on failure
+HostCtx* host_ctx_acquire(int device);               // nullptr + error set on failure; the caller owns it until release
+void host_ctx_release(HostCtx* c);                   // back to the pool (block above the keep limit freed; surplus contexts destroyed)
 hipError_t host_ctx_reserve(HostCtx* c, size_t bytes);  // grows the block (contents are not preserved)
-void host_ctx_release_large(HostCtx* c);             // frees the block if it is above the keep limit
+class HostCtxLease {
+public:
+    explicit HostCtxLease(int device) : ctx(host_ctx_acquire(device)) {}
+    HostCtxLease(const HostCtxLease&) = delete;
+    HostCtxLease& operator=(const HostCtxLease&) = delete;
+    ~HostCtxLease() { if (ctx) host_ctx_release(ctx); }
+    HostCtx* ctx;
+};
 
 }  // namespace mcr

@@ -205,12 +205,18 @@ def run_sharded_bands(params, rng_or_seed, stream_id: int, n_total: int, working
 
 
 def run_sharded_histogram(params, rng_or_seed, stream_id: int, n_total: int, working_months: int, n_bins: int = 100,
-                          value_range: Optional[Tuple[float, float]] = None):
-    """BASELINE configs[3] on N GPUs (success counts + histogram of successful final balances, no trajectories):
-    every rank simulates its shard of the global path range with the summary-output kernel (49 B/path, kept in its
-    own HBM), then the counter block and the histogram bins are summed across ranks.  With ``value_range`` the bin
-    edges are fixed and the exchange is the two sum all-reduces only; without it the cohort's min/max are reduced
-    first (``np.histogram`` semantics on the union of the shards).  Returns the same dict on every rank."""
+                          value_range: Optional[Tuple[float, float]] = None, hist_edges=None):
+    """BASELINE configs[3] on N GPUs (success counts + histogram of successful final balances, no trajectories).
+
+    * FIXED edges — ``value_range=(lo, hi)`` (``np.histogram(x, bins=n_bins, range=...)``) or explicit ascending
+      ``hist_edges`` (``np.histogram(x, bins=hist_edges)``; e.g. ``np.geomspace`` for log-spaced bins): every rank runs the
+      COUNT-ONLY kernel over its shard of the global path range and each lane bins its own final balance inside it
+      (``mcr_outputs.hist_bins``).  No per-path buffer, no second kernel, and the exchange is ONE sum all-reduce of the
+      integer block ``[success, paths, wr_obs[ry], ruin_bins[ry+2], hist_bins[n_bins]]`` — the north-star's shape.
+    * data-ranged edges (neither given; ``np.histogram(x, bins=n_bins)`` on the union of the shards): the summary-output
+      kernel keeps 49 B/path in the rank's HBM, the cohort's min/max are reduced, then the bins (three collectives).
+
+    Returns the same dict on every rank; ``exchange`` names the collectives that ran."""
     import torch
     import torch.distributed as dist
 
@@ -220,6 +226,21 @@ def run_sharded_histogram(params, rng_or_seed, stream_id: int, n_total: int, wor
     rank, world = (dist.get_rank(), dist.get_world_size()) if is_active() else (0, 1)
     begin, count = shard_range(int(n_total), rank, world)
     dev = torch.cuda.current_device()
+    if hist_edges is not None or value_range is not None:
+        edges = E.hist_edge_array(hist_edges) if hist_edges is not None else E.uniform_hist_edges(value_range, n_bins)
+        batch = E.DeviceBatch(params, working_months, max(count, 1), want="count", device=dev, hist_edges=edges)
+        if count > 0:
+            batch.launch(rng_or_seed, stream_id, begin, count)
+        vec = batch.reduce_vec
+        if world > 1:
+            if dist.get_backend() != "nccl":
+                vec = vec.cpu()
+            all_reduce_sum_(vec)
+        host = vec.cpu().numpy()
+        n_fixed = host.shape[0] - (edges.shape[0] - 1)
+        return {"counts": unpack_counts(host[:n_fixed], batch.sizes.retirement_years), "shard": (begin, count),
+                "hist_bins": host[n_fixed:].copy(), "hist_edges": edges,
+                "exchange": "none (1 GPU)" if world == 1 else f"1 all-reduce(sum) of {host.shape[0]} int64 words"}
     batch = E.DeviceBatch(params, working_months, max(count, 1), want="summary", device=dev)
     if count > 0:
         batch.launch(rng_or_seed, stream_id, begin, count)
@@ -228,8 +249,10 @@ def run_sharded_histogram(params, rng_or_seed, stream_id: int, n_total: int, wor
         all_reduce_sum_(vec)
     red = unpack_counts(vec.cpu().numpy(), batch.sizes.retirement_years)
     bins, edges = A.success_histogram(
-        batch.summary["final_balance"][:count], batch.success[:count], n_bins, value_range=value_range,
-        reduce_range=all_reduce_minmax_ if (world > 1 and value_range is None) else None,
+        batch.summary["final_balance"][:count], batch.success[:count], n_bins,
+        reduce_range=all_reduce_minmax_ if world > 1 else None,
         reduce_bins=all_reduce_sum_ if world > 1 else None,
     )
-    return {"counts": red, "shard": (begin, count), "hist_bins": bins, "hist_edges": edges}
+    return {"counts": red, "shard": (begin, count), "hist_bins": bins, "hist_edges": edges,
+            "exchange": "none (1 GPU)" if world == 1 else
+            "all-reduce(sum) of the counter vector + all-reduce(min,max) of the range + all-reduce(sum) of the bins"}

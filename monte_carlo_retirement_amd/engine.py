@@ -51,6 +51,28 @@ def _as_rng(seed) -> McrRng:
     return N.philox_rng(int(seed))
 
 
+def hist_edge_array(edges) -> np.ndarray:
+    """Bin edges of the in-kernel final-balance histogram as the contiguous float64 array the ABI wants;
+    ``ValueError`` unless they are finite, ascending and 2..MCR_MAX_HIST_BINS+1 long (np.histogram's own rule)."""
+    e = np.ascontiguousarray(np.asarray(edges, dtype=np.float64).reshape(-1))
+    if not (2 <= e.shape[0] <= N.MCR_MAX_HIST_BINS + 1):
+        raise ValueError(f"hist_edges: need 2..{N.MCR_MAX_HIST_BINS + 1} edges, got {e.shape[0]}")
+    if not np.all(np.isfinite(e)) or np.any(e[1:] < e[:-1]):
+        raise ValueError("hist_edges must be finite and increase monotonically")
+    return e
+
+
+def uniform_hist_edges(value_range, n_bins: int) -> np.ndarray:
+    """The edges ``np.histogram(x, bins=n_bins, range=value_range)`` bins on (numpy/lib/_histograms_impl.py:
+    ``_get_outer_edges`` widens a degenerate range by 0.5 either side, then ``np.linspace``)."""
+    lo, hi = (float(v) for v in value_range)
+    if not (np.isfinite(lo) and np.isfinite(hi)) or lo > hi:
+        raise ValueError("value_range must be finite with lo <= hi")
+    if lo == hi:
+        lo, hi = lo - 0.5, hi + 0.5
+    return np.linspace(lo, hi, int(n_bins) + 1, endpoint=True, dtype=np.float64)
+
+
 def run_batch_host(
     params: McrParams,
     seed,
@@ -65,6 +87,7 @@ def run_batch_host(
     device: int = 0,
     path_seeds: Optional[np.ndarray] = None,
     devices: Optional[Sequence[int]] = None,
+    hist_edges: Optional[np.ndarray] = None,
 ) -> Dict[str, np.ndarray]:
     """Simulate paths [path_begin, path_begin+n_paths) on the GPU; numpy arrays out.
 
@@ -78,6 +101,10 @@ def run_batch_host(
     Keys follow ``mcr_outputs``: the six float summary fields + ``success`` (uint8),
     ``trajectory``/``real_trajectory`` ``[T, n]``, ``withdrawal_rate_trajectory`` ``[ry, n]``,
     ``counters`` ``[2]``, ``wr_obs_counts`` ``[ry]``, ``ruin_year_bins`` ``[ry+2]``.
+
+    ``hist_edges``: ascending bin edges ``[n_bins + 1]`` -> ``hist_bins`` ``[n_bins]`` =
+    ``np.histogram(final_balance[success], bins=hist_edges)[0]``, binned inside the path kernel
+    (``mcr_outputs.hist_bins``; no per-path output is needed for it).
     """
     lib = N.load_library()
     N.require_device()
@@ -106,6 +133,13 @@ def run_batch_host(
         res["ruin_year_bins"] = np.zeros(sz.ruin_bins, dtype=np.uint64)
         o.wr_obs_counts = res["wr_obs_counts"].ctypes.data
         o.ruin_year_bins = res["ruin_year_bins"].ctypes.data
+    edges_arr = None
+    if hist_edges is not None:
+        edges_arr = hist_edge_array(hist_edges)
+        res["hist_bins"] = np.zeros(edges_arr.shape[0] - 1, dtype=np.uint64)
+        o.hist_edges = edges_arr.ctypes.data
+        o.hist_bins = res["hist_bins"].ctypes.data
+        o.hist_n_bins = edges_arr.shape[0] - 1
     inj = None
     inj_arr = None
     if injected_shocks is not None:
@@ -182,7 +216,7 @@ class DeviceBatch:
     """
 
     def __init__(self, params: McrParams, working_months: int, n_paths: int, want: str = "count",
-                 device: int = 0):
+                 device: int = 0, hist_edges=None):
         import torch
 
         if want not in ("count", "summary", "full"):
@@ -201,10 +235,15 @@ class DeviceBatch:
         # counters | wr_obs_counts | ruin_year_bins live in ONE int64 vector: the path's single exchange step
         # across GPUs is one all-reduce(sum) of it
         ry_ = self.sizes.retirement_years
-        self.reduce_vec = torch.zeros(N.MCR_N_COUNTERS + ry_ + self.sizes.ruin_bins, dtype=i64, device=dev)
+        self.hist_edges = None if hist_edges is None else hist_edge_array(hist_edges)
+        n_hist = 0 if self.hist_edges is None else self.hist_edges.shape[0] - 1
+        n_fixed = N.MCR_N_COUNTERS + ry_ + self.sizes.ruin_bins
+        self.reduce_vec = torch.zeros(n_fixed + n_hist, dtype=i64, device=dev)
         self.counters = self.reduce_vec[:N.MCR_N_COUNTERS]
         self.wr_obs_counts = self.reduce_vec[N.MCR_N_COUNTERS:N.MCR_N_COUNTERS + ry_]
-        self.ruin_year_bins = self.reduce_vec[N.MCR_N_COUNTERS + ry_:]
+        self.ruin_year_bins = self.reduce_vec[N.MCR_N_COUNTERS + ry_:n_fixed]
+        self.hist_bins = self.reduce_vec[n_fixed:] if n_hist else None
+        self._hist_edges_dev = torch.as_tensor(self.hist_edges, device=dev) if n_hist else None
         self.summary = {}
         self.success = None
         self.trajectory = self.real_trajectory = self.withdrawal_rate_trajectory = None
@@ -226,6 +265,10 @@ class DeviceBatch:
         o.counters = self.counters.data_ptr()
         o.wr_obs_counts = self.wr_obs_counts.data_ptr()
         o.ruin_year_bins = self.ruin_year_bins.data_ptr()
+        if n_hist:
+            o.hist_edges = self._hist_edges_dev.data_ptr()
+            o.hist_bins = self.hist_bins.data_ptr()
+            o.hist_n_bins = n_hist
         for k, t in self.summary.items():
             setattr(o, k, t.data_ptr())
         if self.success is not None:

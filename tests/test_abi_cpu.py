@@ -39,7 +39,29 @@ def test_struct_layout_matches_header():
     assert C.sizeof(N.McrStream) == 32
     assert C.sizeof(N.McrParams) == 17 * 8 + 4 * 4 + N.MCR_MAX_STREAMS * 32
     assert C.sizeof(N.McrSizes) == 24
-    assert C.sizeof(N.McrOutputs) == 14 * 8
+    assert C.sizeof(N.McrOutputs) == 17 * 8
+
+
+def test_struct_layout_matches_what_a_c_compiler_sees(tmp_path):
+    """sizeof / offsetof of every ABI struct as gcc lays them out from include/mcr.h (C99) vs the ctypes mirrors."""
+    import subprocess
+
+    structs = {"mcr_stream": N.McrStream, "mcr_params": N.McrParams, "mcr_sizes": N.McrSizes, "mcr_outputs": N.McrOutputs,
+               "mcr_rng": N.McrRng}
+    lines = []
+    for cname, T in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in T._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mcr.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)])
+    seen = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, T in structs.items():
+        assert int(seen[cname]) == C.sizeof(T), cname
+        for fname, _ in T._fields_:
+            assert int(seen[f"{cname}.{fname}"]) == getattr(T, fname).offset, f"{cname}.{fname}"
 
 
 def test_host_derivations_match_reference(lib):
