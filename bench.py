@@ -12,7 +12,11 @@ shard across ranks by GLOBAL path index (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: algorithmic fp64 ops / measured
 kernel time vs the fp64 vector-issue peak) and `cpu_baseline` (the CPU oracle timed on this box's
-host cores on a bounded sample of the same workload).
+host cores on a bounded sample of the same workload), plus one block per remaining BASELINE config:
+`accuracy_10k` (configs[0]'s 10k-path fixture), `hbm_kernels` (configs[2]), `s60` (configs[3]) and
+`search` (configs[4]: the whole bracket + bisection search at 50 000 paths per probe and the 10^6-path
+final run, through the drop-in class).  `config.ranks_seen` / `config.devices` say what the process
+group actually contained.
 """
 
 from __future__ import annotations
@@ -30,9 +34,15 @@ sys.path.insert(0, REPO)
 WORKING_MONTHS = 233          # config.json scenario, SURVEY §8 C1: 833 months/path, T=71
 ALGO_OPS_PER_PATH = 233 * 79 + 600 * 167  # 79 ops/accumulation month, 167/retirement month
 # fp64 vector peak: 78.6 TFLOP/s (AMD spec; = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz x 2 flop/FMA).
-# The path has no FMAs by construction (-ffp-contract=off, reference rounding), so one algorithmic
-# op = one lane-instruction = 1 flop: the applicable issue ceiling is 39.3 T fp64 lane-ops/s.
+# The algorithmic count of SURVEY 8d is in OPERATIONS of the reference's arithmetic (an add, a multiply, a division and
+# an exp call each count 1), whose roundings the state machine reproduces one by one (-ffp-contract=off), so the
+# applicable ceiling is one operation per lane and clock: 39.3 T fp64 lane-ops/s.  (The kernel does issue FMAs where
+# the reference's roundings allow: inside exp / log / sincos, the Newton steps of the divisions, a + b z.)
+# MEASURED issue ceiling: tools/ubench/valu_cost.hip puts a dependent-free stream of fp64 add / mul / fma at 4.8-5.3
+# cycles per wave-instruction on a SIMD (profiles/valu_cost_gfx950.txt), i.e. ~33 T lane-ops/s at the 2.27 GHz the
+# chip holds under this load; `roofline.frac_of_measured_issue_ceiling` is quoted against that.
 FP64_LANE_OPS_PEAK_T = 39.3
+FP64_MEASURED_ISSUE_CEILING_T = 33.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -56,6 +66,46 @@ def cpu_baseline(params, n_threads: int, paths_per_thread: int):
         th.join()
     dt = time.perf_counter() - t0
     return sum(done) / dt, dt
+
+
+def host_cpu_info():
+    """What the CPU baseline ran on (`nproc` and CPU model stated)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return {"host_cores": os.cpu_count(), "usable_cores": usable, "cpu_model": model}
+
+
+def cpu_baseline_block(params, n_threads: int, paths_per_thread: int, single_thread_paths: int):
+    """`cpu_baseline` of the JSON line: the oracle on `n_threads` host threads (the figure `value` reports) and on ONE
+    thread, the box's core count and CPU model beside them."""
+    info = host_cpu_info()
+    n_threads = max(1, min(int(n_threads), int(info["usable_cores"])))
+    v1, s1 = cpu_baseline(params, 1, single_thread_paths)
+    v, secs = cpu_baseline(params, n_threads, paths_per_thread)
+    return {
+        "value": v,
+        "unit": "paths/s",
+        "cores": n_threads,
+        "kind": "port",
+        "sample": f"{n_threads} threads x {paths_per_thread} paths of the same workload "
+                  f"(oracle/mcr_oracle.c, scalar fp64, {secs:.1f} s wall)",
+        "single_thread": {"value": v1, "unit": "paths/s", "cores": 1,
+                          "sample": f"1 thread x {single_thread_paths} paths ({s1:.1f} s wall)"},
+        **info,
+        "reference_cpython": "113 paths/s on 1 core, 574 paths/s with 8 processes (BASELINE.md 2: the reference's own NumPy/CPython "
+                             "path, survey container, 8 vCPU Xeon 2.1 GHz; its files cannot travel to this box)",
+    }
 
 
 def aux_hbm_kernels(torch, n):
@@ -146,13 +196,20 @@ def accuracy_10k():
             "source": "tests/golden/metric_10k_config_json.{json,npz} (the reference's own flags on identical shocks)"}
 
 
-def s60_block(torch, dist, world, n_total, reps=3, grouped=None):
+S60_EDGES = (1.0, 1.0e12, 100)   # fixed log-spaced bins of the s60 block: np.geomspace(lo, hi, n + 1)
+
+
+def s60_block(torch, dist, world, n_total, reps=3, grouped=None, fixed_edges=True):
     """North-star shape (BASELINE configs[3]): S60 = config.json with initial_balance=2e6,
     inv1 volatility 0.15, rho=0.3, wm=120 (720-month paths); success counts + 100-bin histogram of the
-    successful final balances over `n_total` paths IN TOTAL, sharded by global path range over the ranks
-    (`distributed.run_sharded_histogram`: counter/bin all-reduce + a min/max all-reduce for the range).
-    End to end per repetition: buffer allocation, summary-output kernel (49 B/path), min/max + bins,
-    collectives, result download.  Not part of `value`."""
+    successful final balances over `n_total` paths IN TOTAL, sharded by global path range over the ranks.
+    fixed_edges (the `s60` block): `distributed.run_sharded_histogram(hist_edges=...)` — the COUNT-ONLY kernel bins
+    every path's final balance itself on fixed log-spaced edges, nothing per path touches HBM, and the
+    ranks exchange ONE all-reduce of the integer block [counters | year bins | histogram].
+    Otherwise (`s60_data_ranged`): np.histogram's data-ranged edges — summary-output kernel (49 B/path), min/max +
+    bins (K2), three collectives.  End to end per repetition incl. allocation, collectives, download.  Not part of `value`."""
+    import numpy as np
+
     from monte_carlo_retirement_amd import Config, params_from_config
     from monte_carlo_retirement_amd import distributed as D
 
@@ -161,13 +218,14 @@ def s60_block(torch, dist, world, n_total, reps=3, grouped=None):
                             equity_inflation_correlation=0.3, seed=12345))
     p = params_from_config(cfg)
     grouped = world > 1 if grouped is None else grouped
+    edges = np.geomspace(S60_EDGES[0], S60_EDGES[1], S60_EDGES[2] + 1) if fixed_edges else None
     times, r = [], None
     for _ in range(reps):
         if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        r = D.run_sharded_histogram(p, 12345, 1, n_total, 120, n_bins=100)
+        r = D.run_sharded_histogram(p, 12345, 1, n_total, 120, n_bins=100, hist_edges=edges)
         torch.cuda.synchronize()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         if grouped:
@@ -179,13 +237,103 @@ def s60_block(torch, dist, world, n_total, reps=3, grouped=None):
     return {
         "workload": f"BASELINE configs[3] / north-star shape: S60 (config.json, initial_balance=2e6, inv1 vol 0.15, rho=0.3), "
                     f"wm=120 (720 months/path), {n_total} paths in total over {world} GPU(s), success count + 100-bin "
-                    "histogram of successful final balances",
+                    "histogram of successful final balances"
+                    + (f" on fixed edges np.geomspace({S60_EDGES[0]:g}, {S60_EDGES[1]:g}, 101), binned inside the count-only path kernel"
+                       if fixed_edges else " on np.histogram's data-ranged edges (summary-output kernel + min/max + bin kernels)"),
         "n_paths_total": n_total, "n_gpus": world, "seconds": sec, "paths_per_s": n_total / sec,
         "success_probability": c.success / max(1, c.paths), "paths_counted": c.paths,
-        "hist_total": int(r["hist_bins"].sum()),
-        "exchange": "none (1 GPU)" if world == 1 else "all-reduce(sum) of the counter/bin vectors + all-reduce(min,max) of the histogram range",
+        "hist_total": int(r["hist_bins"].sum()), "hist_outside_edges": int(c.success - int(r["hist_bins"].sum())),
+        "exchange": r["exchange"],
         "note": "end to end incl. allocation and download; median of %d repetitions, max over ranks" % reps,
     }
+
+
+def search_block(torch, dist, world, device, grouped, reps=3):
+    """BASELINE configs[4] (SURVEY 8d B5): `find_minimum_working_months` — bracket, bisection, verification window;
+    reference backend/simulation.py:1138-1342 — on the config.json scenario with num_simulations_search = 50 000 paths per
+    probed month, then the final run of num_simulations_main = 10^6 paths, all through the drop-in class
+    (`RetirementMonteCarloSimulator`).  Probes are count-only launches; the months of one round share their accumulation
+    sweep.  Under a process group the probes of a round are split by candidate month over the ranks (one all-reduce per
+    round) and the final run is sharded by path range; the curve must then equal the single-GPU search's, which every
+    rank replays locally as a check (`distributed.local_only`).  Not part of `value`."""
+    import hashlib
+
+    from monte_carlo_retirement_amd import Config
+    from monte_carlo_retirement_amd import distributed as D
+    from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
+
+    with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
+        cfg = Config(**dict(json.load(fh), seed=12345, num_simulations_search=50_000, num_simulations_main=1_000_000))
+
+    def fence():
+        if grouped:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def wall_max(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if grouped:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def one_search():
+        sim = RetirementMonteCarloSimulator(cfg, device=device)
+        calls, inner = [], sim._probe_many          # one call = one round of launches (+ one all-reduce under a group)
+        sim._probe_many = lambda months, n: (calls.append(len(months)), inner(months, n))[1]
+        fence()
+        t0 = time.perf_counter()
+        months, prob, curve = sim.find_minimum_working_months(verbose=False)
+        torch.cuda.synchronize()
+        return sim, months, prob, curve, calls, wall_max(time.perf_counter() - t0)
+
+    one_search()                                   # untimed: first-use allocations, module load of the probe kernels
+    runs = [one_search() for _ in range(reps)]
+    runs.sort(key=lambda r: r[-1])
+    sim, months, prob, curve, calls, sec = runs[len(runs) // 2]
+    assert all(r[3] == curve for r in runs), "the search is deterministic: every repetition must replay the same curve"
+    probes = len(curve)
+    out = {
+        "workload": "BASELINE configs[4]: config.json, num_simulations_search=50000 paths per probed month, bracket + bisection + "
+                    f"verification window, then the final run of 1000000 paths, over {world} GPU(s)",
+        "n_gpus": world, "paths_per_probe": cfg.num_simulations_search,
+        "months_found": months, "probability_pct": prob, "probes": probes,
+        "probe_rounds": len(calls), "months_evaluated": sum(calls), "largest_round": max(calls) if calls else 0,
+        "search_seconds": sec, "ms_per_probe": sec / max(1, probes) * 1e3,
+        "probe_paths_per_s": probes * cfg.num_simulations_search / sec,
+        "curve_sha16": hashlib.sha256(json.dumps(curve, sort_keys=True).encode()).hexdigest()[:16],
+        "curve_head": curve[:3], "curve_tail": curve[-2:],
+        "probe_split": ("by candidate month over the ranks, 1 all-reduce(sum) of the per-candidate counters per round"
+                        if world > 1 else "none (1 GPU): the months of a round share one accumulation sweep"),
+    }
+    if D.is_active():
+        with D.local_only():                       # the same search on this rank's GPU alone
+            lsim = RetirementMonteCarloSimulator(cfg, device=device)
+            lm, lp, lcurve = lsim.find_minimum_working_months(verbose=False)
+        same = torch.tensor([1 if (lm, lp, lcurve) == (months, prob, curve) else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        out["equals_single_gpu_search"] = bool(int(same.item()))
+    # the final run (simulation.py:1130-1136 of the caller's flow: use_final_seeds, run, success probability)
+    if months >= 0:
+        sim.use_final_seeds()
+        sim.run_monte_carlo_simulations(months, cfg.num_simulations_main)      # untimed first call: allocations
+        times = []
+        res = None
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            res = sim.run_monte_carlo_simulations(months, cfg.num_simulations_main)
+            torch.cuda.synchronize()
+            times.append(wall_max(time.perf_counter() - t0))
+        fsec = sorted(times)[len(times) // 2]
+        out.update({
+            "final_run_paths": cfg.num_simulations_main, "final_run_seconds": fsec,
+            "final_run_paths_per_s": cfg.num_simulations_main / fsec,
+            "final_success_probability_pct": sim._success_probability(res[0]),
+            "final_run_outputs": "the reference's 7-tuple: per-path summary frame (10^6 x 7), nominal / real trajectory bands, "
+                                 "withdrawal-rate bands, 5 sampled paths, observation counts",
+            "end_to_end_seconds": sec + fsec,
+        })
+    return out
 
 
 def launch_ranks(n_ranks: int) -> int:
@@ -193,21 +341,37 @@ def launch_ranks(n_ranks: int) -> int:
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, as torch.distributed.run would), wait, and
     return non-zero if any rank failed.  The parent never imports torch or touches a GPU; children are plain
     child processes (nothing is exec'ed over a process that has initialised the GPU).  Rank 0 inherits stdout,
-    so its JSON line is this command's JSON line."""
+    so its JSON line is this command's JSON line.  Every rank's stderr goes to a file of its own; the parent
+    replays rank 0's in full and the tail of every rank that failed or had to be killed.
+    Nothing here can wait forever: an overall deadline (MCR_BENCH_DEADLINE_S, default 1200 s — ranks stuck in the
+    RCCL rendezvous are the likeliest first-contact failure on an 8-GPU node) and, once one rank has failed, 30 s
+    for the others; children that are still running then are killed by PID and the exit code is non-zero."""
     import socket
     import subprocess
+    import tempfile
 
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="mcr_bench_ranks_")
+    procs, logs = [], []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # The host driver of this pool supports only dmabuf IPC: with the legacy IPC mode RCCL's (and torch's) cross-process
+        # buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image exports 0 already; keep a caller's choice.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        logs.append(open(os.path.join(logdir, f"rank{r}.stderr"), "w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc, pending, deadline = 0, set(range(n_ranks)), None
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=logs[r]))
+
+    def tail(r, n_lines=40):
+        logs[r].flush()
+        logs[r].seek(0)
+        return logs[r].read().splitlines()[-n_lines:]
+
+    overall = time.monotonic() + float(os.environ.get("MCR_BENCH_DEADLINE_S", "1200"))
+    rc, pending, deadline, killed = 0, set(range(n_ranks)), None, []
     while pending:
         for r in sorted(pending):
             code = procs[r].poll()
@@ -219,13 +383,28 @@ def launch_ranks(n_ranks: int) -> int:
                 print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr, flush=True)
                 if deadline is None:
                     deadline = time.monotonic() + 30.0  # the others are stuck in a collective: do not wait for them
-        if deadline is not None and time.monotonic() > deadline:
-            for r in pending:
+        now = time.monotonic()
+        if pending and ((deadline is not None and now > deadline) or now > overall):
+            why = "a peer failed" if (deadline is not None and now > deadline) else "overall deadline reached"
+            killed = sorted(pending)
+            print(f"bench.py: killing ranks {killed} ({why})", file=sys.stderr, flush=True)
+            for r in killed:
                 procs[r].kill()  # exact PIDs this launcher started
-            for r in pending:
+            for r in killed:
                 procs[r].wait()
+            rc = rc or 124
             break
         time.sleep(0.05)
+    logs[0].flush()
+    logs[0].seek(0)
+    sys.stderr.write(logs[0].read())
+    for r in range(1, n_ranks):
+        if procs[r].returncode != 0 or r in killed:
+            for line in tail(r):
+                print(f"[rank {r}] {line}", file=sys.stderr)
+    sys.stderr.flush()
+    for f in logs:
+        f.close()
     return rc
 
 
@@ -242,8 +421,10 @@ def main():
     ap.add_argument("--aux-paths", type=int, default=10_000_000, help="paths of the BASELINE configs[2] block (hbm_kernels)")
     ap.add_argument("--no-s60", action="store_true", help="skip the north-star S60 block")
     ap.add_argument("--s60-paths", type=int, default=100_000_000, help="TOTAL paths of the BASELINE configs[3] block (s60)")
+    ap.add_argument("--no-search", action="store_true", help="skip the BASELINE configs[4] block (search)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-paths-per-thread", type=int, default=160_000)
+    ap.add_argument("--cpu-single-thread-paths", type=int, default=20_000)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -270,11 +451,35 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+
+        # a finite rendezvous / collective timeout: a rank that never arrives fails the job instead of hanging it
+        tmo = datetime.timedelta(seconds=float(os.environ.get("MCR_BENCH_PG_TIMEOUT_S", "600")))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
     comm_dev = torch.device("cuda", device) if (not grouped or args.backend == "nccl") else torch.device("cpu")
+    # What the process group actually contains: an all-reduce of ones (how many ranks took part in a collective) and
+    # every rank's device, gathered to all ranks.
+    me = {"rank": rank, "local_rank": local_rank, "device_index": device, "device_name": torch.cuda.get_device_name(device),
+          "visible_devices": torch.cuda.device_count(), "pid": os.getpid()}
+    # (the marketing name needs /opt/amdgpu/share/libdrm/amdgpu.ids, which a box may lack: "AMD Radeon Graphics"; the
+    #  architecture string, CU count and memory size identify the part either way)
+    props = torch.cuda.get_device_properties(device)
+    for key, attr in (("gcn_arch", "gcnArchName"), ("compute_units", "multi_processor_count"), ("total_memory", "total_memory"),
+                      ("pci_bus_id", "pci_bus_id")):
+        if hasattr(props, attr):
+            me[key] = getattr(props, attr)
+    if grouped:
+        ones = torch.ones(1, dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        devices_seen = [None] * dist.get_world_size()
+        dist.all_gather_object(devices_seen, me)
+        backend_seen = dist.get_backend()
+    else:
+        ranks_seen, devices_seen, backend_seen = 1, [me], None
 
     with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
         cfg = Config(**dict(json.load(fh), seed=12345))
@@ -339,12 +544,18 @@ def main():
     # local running totals of the timed steps; with N ranks the last exchange holds the job's totals
     counters = (exch2[(args.steps - 1) & 1] if grouped else batch.reduce_vec)[:2].cpu().tolist()
 
-    s60 = None
-    if not args.no_s60:
+    def guarded(fn, *a, **kw):
         try:
-            s60 = s60_block(torch, dist, world, args.s60_paths, grouped=grouped)
-        except Exception as exc:  # never lose the headline line to the auxiliary block
-            s60 = {"error": f"{type(exc).__name__}: {exc}"}
+            return fn(*a, **kw)
+        except Exception as exc:  # never lose the headline line to an auxiliary block
+            return {"error": f"{type(exc).__name__}: {exc}"}
+
+    s60 = s60_ranged = search = None
+    if not args.no_s60:
+        s60 = guarded(s60_block, torch, dist, world, args.s60_paths, grouped=grouped, fixed_edges=True)
+        s60_ranged = guarded(s60_block, torch, dist, world, args.s60_paths, grouped=grouped, fixed_edges=False)
+    if not args.no_search:
+        search = guarded(search_block, torch, dist, world, device, grouped)
 
     if rank == 0:
         total_paths = n * world * args.steps
@@ -375,6 +586,9 @@ def main():
                 "rng": "Philox4x32-10 + Box-Muller, counter=(path,month,stream), key=seed",
                 "parallelism": f"path-range sharding x{world}" + (
                     f" + 1 all-reduce(sum) of the {exch.numel()}-word counter/bin vector per step ({args.backend}), overlapped with the next step's compute" if grouped else ""),
+                "ranks_seen": ranks_seen,          # all-reduce(sum) of one 1 per rank: the ranks that took part in a collective
+                "backend": backend_seen,           # torch.distributed backend of the group ("nccl" = RCCL), None without a group
+                "devices": devices_seen,           # every rank's own report (all_gather_object)
             },
             "roofline": {
                 "kernel": "mcr::path_kernel<0, 0, true, false>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
@@ -383,11 +597,16 @@ def main():
                 "peak": FP64_LANE_OPS_PEAK_T,
                 "unit": "TFLOP/s",
                 "frac": achieved_t / FP64_LANE_OPS_PEAK_T,
+                "measured_issue_ceiling": FP64_MEASURED_ISSUE_CEILING_T,
+                "frac_of_measured_issue_ceiling": achieved_t / FP64_MEASURED_ISSUE_CEILING_T,
                 "traffic": traffic,
                 "kernel_ms": kern_ms,
                 "algorithmic_ops_per_path": ALGO_OPS_PER_PATH,
-                "note": "no dense contraction and ~0 HBM bytes/path in this variant: the bound is fp64 VALU "
-                        "issue (SURVEY 8d). peak = 78.6 TFLOP/s spec / 2 (the path has no FMAs: 1 op = 1 flop)",
+                "note": "no dense contraction and ~0 HBM bytes/path in this variant: the bound is fp64 VALU issue (SURVEY 8d). "
+                        "achieved = SURVEY 8d's SOURCE-LEVEL operation count of the reference's arithmetic (each + - * / min max compare "
+                        "and each exp / log / sqrt / sin / cos call = 1) per second; peak = 78.6 TFLOP/s spec / 2 = one fp64 lane-operation "
+                        "per lane and clock.  The kernel itself issues FMAs where the reference's roundings allow (growth factors, "
+                        "Newton steps of the divisions), so this is a count of useful work against the issue peak, not an instruction count",
             },
             "success_probability": counters[0] / max(1, counters[1]),
             "paths_counted": counters[1],
@@ -398,18 +617,17 @@ def main():
             out["accuracy_10k"] = {"error": f"{type(exc).__name__}: {exc}"}
         if s60 is not None:
             out["s60"] = s60
+            out["s60_data_ranged"] = s60_ranged
+        if search is not None:
+            out["search"] = search
         if not args.no_aux and world == 1:
-            out["hbm_kernels"] = aux_hbm_kernels(torch, args.aux_paths)
-        if not args.no_cpu_baseline and world == 1:
-            v, secs = cpu_baseline(params, args.cpu_threads, args.cpu_paths_per_thread)
-            out["cpu_baseline"] = {
-                "value": v,
-                "unit": "paths/s",
-                "cores": args.cpu_threads,
-                "kind": "port",
-                "sample": f"{args.cpu_threads} threads x {args.cpu_paths_per_thread} paths of the same workload "
-                          f"(oracle/mcr_oracle.c, scalar fp64, {secs:.1f} s wall)",
-            }
+            out["hbm_kernels"] = guarded(aux_hbm_kernels, torch, args.aux_paths)
+        if not args.no_cpu_baseline:
+            # rank 0 only; with N > 1 the other ranks wait at the closing barrier (outside every timed region), so the
+            # sample is a quarter of the single-GPU run's
+            scale = 1 if world == 1 else 4
+            out["cpu_baseline"] = guarded(cpu_baseline_block, params, args.cpu_threads, max(1, args.cpu_paths_per_thread // scale),
+                                          max(1, args.cpu_single_thread_paths // scale))
         print(json.dumps(out), flush=True)
     if grouped:
         dist.barrier()

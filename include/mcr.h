@@ -345,8 +345,11 @@ int mcr_row_quantiles_last_fallback_rows(void);
  * or a synchronising host implementation), and return 0.  About ten such calls per invocation, the largest the two
  * sub-histogram blocks (n_rows * 64 KiB) and the cell lists (n_rows * 96 KiB).  Every rank must call with the same
  * n_rows, n_total, q; every rank returns the same exact quantiles.  Needs rank 0 to hold >= 4096 entries, world <= 64,
- * fewer than 16 quantiles: otherwise MCR_ERR_UNSUPPORTED (use the stepwise radix select above).  Synchronises
- * hip_stream once.  scratch: mcr_row_quantiles_scratch_bytes(n_rows, n_q, n_local).
+ * fewer than 16 quantiles: otherwise MCR_ERR_UNSUPPORTED (use the stepwise radix select above) — on EVERY rank: the one
+ * condition that depends on a single rank's shard (rank 0's first sample) is agreed through the first `reduce` call, so no
+ * rank leaves while its peers wait in a collective.  A `reduce` callback that fails on one rank only is the caller's to
+ * avoid (the peers would wait in the collective it skipped).  Synchronises hip_stream a few times.
+ * scratch: mcr_row_quantiles_scratch_bytes(n_rows, n_q, n_local).
  */
 #define MCR_DT_I32 0
 #define MCR_DT_I64 1

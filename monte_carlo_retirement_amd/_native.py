@@ -217,7 +217,9 @@ _lib_lock = threading.Lock()
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
+    """csrc/libmcr_hip.so next to this file; MCR_HIP_LIBRARY names another build of the same ABI (A/B measurements of
+    compile-time variants, tools/)."""
+    return os.environ.get("MCR_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
 
 
 def _declare(lib: C.CDLL) -> None:

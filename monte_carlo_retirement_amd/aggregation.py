@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -62,21 +63,39 @@ def row_quantiles(rows, n: int, qs: Sequence[float], device: int = 0, reduce_cou
     n_rows = int(rows.shape[0])
     q = _pandas_q(qs)
     dev = rows.device
-    # quantiles [n_rows, n_q] (float64) and counts [n_rows] (uint64) share ONE device buffer: one download, one sync
-    res = torch.empty(n_rows * (len(q) + 1), dtype=torch.float64, device=dev)
+    # quantiles [n_rows, n_q] (float64) and counts [n_rows] (uint64) share ONE buffer in PINNED HOST memory, which the
+    # device writes directly (a few KB over the host link): the bracketed route ends with a stream synchronisation of its
+    # own (it reads one word back), after which the results are already on the host — no separate download and second
+    # synchronisation.  The short-row radix route is asynchronous, hence the synchronise below (a no-op after the other).
+    res = _pinned_result(n_rows * (len(q) + 1))
     out, counts = res[:n_rows * len(q)], res[n_rows * len(q):]
     nbytes = int(lib.mcr_row_quantiles_scratch_bytes(n_rows, len(q), int(n)))
     if nbytes <= 0:
         raise ValueError("unsupported number of rows / quantiles")
     scratch = _scratch(scratch_owner, nbytes, dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    cur = torch.cuda.current_stream(dev)
     rc = lib.mcr_row_quantiles(
         rows.data_ptr(), int(rows.stride(0)), n_rows, int(n), q.ctypes.data, len(q),
-        out.data_ptr(), counts.data_ptr(), scratch.data_ptr(), dev.index or 0, C.c_void_p(stream),
+        out.data_ptr(), counts.data_ptr(), scratch.data_ptr(), dev.index or 0, C.c_void_p(cur.cuda_stream),
     )
     N.check(rc, "mcr_row_quantiles")
-    host = res.cpu().numpy()
+    cur.synchronize()
+    host = res.numpy().copy()
     return host[:n_rows * len(q)].reshape(n_rows, len(q)), host[n_rows * len(q):].view(np.uint64).astype(np.int64)
+
+
+_pinned = threading.local()
+
+
+def _pinned_result(n_doubles: int):
+    """A pinned (page-locked, device-visible) float64 host buffer of at least `n_doubles`, cached per calling thread."""
+    import torch
+
+    buf = getattr(_pinned, "buf", None)
+    if buf is None or buf.numel() < n_doubles:
+        buf = torch.empty(max(n_doubles, 4096), dtype=torch.float64, pin_memory=True)
+        _pinned.buf = buf
+    return buf[:n_doubles]
 
 
 def _scratch(owner, nbytes: int, dev):
@@ -100,10 +119,13 @@ def last_fallback_rows() -> int:
     return int(N.load_library().mcr_row_quantiles_last_fallback_rows())
 
 
-#: rows sharded over ranks take the bracketed single-pass route from this many entries per row IN TOTAL (below it the
-#: 4-read radix select is as fast); every shard must hold at least _SHARD_MIN_LOCAL entries (the first sample is rank 0's)
-_SHARDED_BRACKET_MIN_TOTAL = 1 << 21
-_SHARD_MIN_LOCAL = 65536
+#: rows sharded over ranks take the bracketed single-pass route from this many entries per row IN TOTAL; every shard must
+#: hold at least _SHARD_MIN_LOCAL entries (the first sample is rank 0's).  On one GPU the bracketed route wins from 2^14
+#: entries (csrc/mcr_aggregate.hip: rq_bracket_min_n); sharded, both routes add their collectives — ~10 small all-reduces
+#: here against 8 of the digit histograms there — so the same argument holds per rank once every shard is a few times the
+#: first sample: 2^18 in total with shards of 2^14 and more (round 2 waited for 2^21 / 2^16).
+_SHARDED_BRACKET_MIN_TOTAL = 1 << 18
+_SHARD_MIN_LOCAL = 1 << 14
 
 
 def _row_quantiles_sharded(rows, n_local: int, qs, reduce_counts, n_total: int, scratch_owner=None):

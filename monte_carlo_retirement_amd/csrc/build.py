@@ -41,23 +41,31 @@ def is_stale() -> bool:
 PER_SOURCE_FLAGS = {"mcr_hip.hip": ["-Xarch_device", "-fno-honor-nans"]}
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: str = "") -> str:
+    """`variant` (with `extra_flags`, e.g. ["-DMCR_RQ_UNROLL=8"]): a second library csrc/libmcr_hip_<variant>.so for A/B
+    measurements (selected at run time with MCR_HIP_LIBRARY); the default build is csrc/libmcr_hip.so."""
+    if variant:
+        return _build_to(os.path.join(HERE, f"libmcr_hip_{variant}.so"), f"_{variant}", verbose, extra_flags)
     if not force and not is_stale():
         return TARGET
+    return _build_to(TARGET, "", verbose, extra_flags)
+
+
+def _build_to(target: str, obj_suffix: str, verbose: bool, extra_flags) -> str:
     compile_flags = [f for f in FLAGS if f != "-shared"]
     objs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, src.replace(".hip", f"{obj_suffix}.o"))
         cmd = [hipcc(), *compile_flags, *PER_SOURCE_FLAGS.get(src, []), *extra_flags, "-c", "-o", obj, os.path.join(HERE, src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", TARGET, *objs]
+    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", target, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return TARGET
+    return target
 
 
 if __name__ == "__main__":

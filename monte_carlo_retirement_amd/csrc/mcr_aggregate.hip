@@ -51,7 +51,8 @@ struct RqRow {  // per-row selection state, lives in the caller's scratch buffer
 };
 
 constexpr unsigned long long kRqKeyPosInf = 0xFFF0000000000000ull;   // key_of(+inf): the largest non-NaN key
-constexpr double kRqBracketSigmas = 5.0;   // half-width of a bracket in binomial standard deviations of the sample rank
+constexpr double kRqBracketSigmas = 4.5;   // half-width of a bracket in binomial standard deviations of the sample rank: a side misses with
+                                           // probability 3.4e-6 (one row in ~150 calls of 136 rows x 7 quantiles takes the radix route); 5.0 cost 10 % more candidates
 
 // Disjoint, ascending key intervals of one row (from its sample) and what the bracket pass counted for them.
 struct RqBracket {
@@ -67,7 +68,16 @@ struct RqBracket {
     unsigned int cand_count;                       // values appended to the row's candidate buffer
     unsigned int fallback;                         // 1: the row takes the full radix passes
     unsigned int open_lo, open_hi;                 // coarse level: bit j = quantile j's window ran off the first sample
+    // bucket table of the slab pass (rq_slab_kernel): bucket(x) = clamp((int)fma(x, lut_s, lut_c), 0, kRqLutSize - 1), an equal-width
+    // grid in VALUE over the span of the bounds; lut_ok = 1 when no bucket holds more than two of the row's bounds
+    double lut_s, lut_c;
+    unsigned int lut_ok;
+    unsigned int lut_pad;
 };
+#ifndef MCR_RQ_LUT_SIZE
+#define MCR_RQ_LUT_SIZE 2048
+#endif
+constexpr int kRqLutSize = MCR_RQ_LUT_SIZE;
 constexpr int kRqTiny = 4096;              // first sample: sorted in LDS by one workgroup per row
 constexpr double kRqCoarseSigmas = 7.0;    // its brackets leave room for the second sample's own 5-sigma window
 constexpr int kRqMaxSubBins = 1024;        // sub-histogram bins per interval (stride of the global histograms)
@@ -445,6 +455,26 @@ __device__ __forceinline__ int rq_sub_bin(unsigned long long key, double x, unsi
     return b < bins - 1 ? b : bins - 1;
 }
 
+// The slab pass compares in the DOUBLE domain (no key conversion per element): "key(x) >= kb" for a key bound kb is
+// "x >= rq_bound_value(kb)" for every non-NaN x — a bound below key(-inf) is "always" (-inf), one above key(+inf) is
+// "never" (a NaN: every comparison with it is false) — except that the double order has ONE zero where the key order
+// has two (key(-0.0) = key(+0.0) - 1).  The slab pass therefore treats -0.0 AS +0.0 throughout: positions come from
+// double comparisons, and a candidate is canonicalised (x + 0.0) before it is binned and stored, so everything
+// downstream sees the key of +0.0.  The quantiles are unchanged as numbers (-0.0 == +0.0).
+constexpr unsigned long long kRqKeyNegInf = 0x000FFFFFFFFFFFFFull;   // key_of(-inf): the smallest non-NaN key
+__device__ __forceinline__ double rq_bound_value(unsigned long long kb) {
+    if (kb <= kRqKeyNegInf) return __longlong_as_double((long long)0xfff0000000000000ull);
+    if (kb > kRqKeyPosInf) return __longlong_as_double(0x7ff8000000000000LL);
+    return value_of(kb);
+}
+__device__ __forceinline__ int rq_lut_bucket(double x, double s, double c) {
+    const int t = (int)__builtin_fma(x, s, c);          // v_cvt_i32_f64: saturates, NaN -> 0; monotone in x for s >= 0
+    return t < 0 ? 0 : (t > kRqLutSize - 1 ? kRqLutSize - 1 : t);
+}
+__device__ __forceinline__ int rq_lut_bucket_of_bound(double bv, double s, double c) {
+    return bv != bv ? kRqLutSize : rq_lut_bucket(bv, s, c);   // a "never" bound lies beyond every bucket
+}
+
 // Merge the brackets [lo_j, hi_j] of n_q quantiles (closed key intervals) into disjoint ascending intervals of one
 // row and set every interval's sub-bin shift for `sub_bits`-bit sub-histograms; counters zeroed.  (One thread.)
 __device__ void rq_make_intervals(RqBracket& B, const unsigned long long* lo, const unsigned long long* hi, int n_q, int sub_bits) {
@@ -483,6 +513,29 @@ __device__ void rq_make_intervals(RqBracket& B, const unsigned long long* lo, co
     }
     for (int k = 0; k <= 2 * kRqMaxQ; ++k) B.pos_count[k] = 0ull;
     B.n_nan = 0ull; B.cand_count = 0u; B.fallback = 0u; B.open_lo = 0u; B.open_hi = 0u;
+    // bucket grid of the slab pass: equal steps of VALUE from the lowest to the highest finite bound
+    {
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        double xa = inf, xb = -inf;
+        for (int i = 0; i < 2 * nb; ++i) {
+            const double v = rq_bound_value((i & 1) ? B.hi[i >> 1] + 1ull : B.lo[i >> 1]);
+            if (v == v && v > -inf && v < inf) { xa = v < xa ? v : xa; xb = v > xb ? v : xb; }
+        }
+        double sc = 0.0, cc = 0.0;
+        if (xb > xa) {
+            sc = (double)(kRqLutSize - 2) / (xb - xa);
+            cc = -xa * sc;
+            if (!(sc > 0.0 && sc < 1.0e300 && cc == cc && cc > -1.0e300 && cc < 1.0e300)) { sc = 0.0; cc = 0.0; }
+        }
+        B.lut_s = sc; B.lut_c = cc; B.lut_pad = 0u;
+        int prev2 = -1, prev1 = -1, ok = 1;       // the bounds ascend: three in one bucket <=> bucket[i] == bucket[i - 2]
+        for (int i = 0; i < 2 * nb; ++i) {
+            const int k = rq_lut_bucket_of_bound(rq_bound_value((i & 1) ? B.hi[i >> 1] + 1ull : B.lo[i >> 1]), sc, cc);
+            if (i >= 2 && k == prev2) ok = 0;
+            prev2 = prev1; prev1 = k;
+        }
+        B.lut_ok = (unsigned int)ok;
+    }
 }
 
 // (1) Coarse brackets.  One workgroup per row sorts the first kRqTiny entries in LDS (bitonic, NaNs last) and takes,
@@ -495,7 +548,7 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
     __shared__ unsigned long long qlo[kRqMaxQ], qhi[kRqMaxQ];
     __shared__ unsigned int nan_n, open_lo, open_hi;
     const int row = blockIdx.x, t = threadIdx.x;
-    if (row == 0 && t == 0) *fb_count = 0u;
+    if (row == 0 && t == 0 && fb_count) *fb_count = 0u;   // (nullptr: the caller zeroes it — row groups on several streams)
     if (t == 0) { nan_n = 0u; open_lo = 0u; open_hi = 0u; }
     __syncthreads();
     const double* r = rows + (int64_t)row * row_stride;
@@ -572,6 +625,18 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
     if (t == 0) { rq_make_intervals(B, qlo, qhi, args.n_q, kRqCoarseSubBits); B.open_lo = open_lo; B.open_hi = open_hi; }
 }
 
+struct RqRefineShared {
+    unsigned long long below[kRqMaxQ], upto[kRqMaxQ], qlo[kRqMaxQ], qhi[kRqMaxQ];
+    unsigned int miss;
+};
+__device__ __forceinline__ unsigned long long rq_ld_u64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int rq_ld_u32(const unsigned int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ void rq_refine_row(int row, int64_t m, const RqArgs& args, const RqBracket* br1, const unsigned int* hist1,
+                              RqBracket* br2, unsigned int* hist2, int sub_bits2, unsigned int* gfill, unsigned int* pre, RqRefineShared& S);
 // (2) and (4) THE counting pass, over the first `n` entries of every row (the sample, then the whole slab).  Every
 // non-NaN key is located among the row's sorted interval bounds by a branch-free binary search (P-entry table in LDS:
 // bound 2b = lo[b], bound 2b+1 = hi[b]+1, padded with ~0; position = number of bounds <= key), counted in a per-thread
@@ -583,7 +648,7 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
 template <int P, bool COMPACT>
 __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void rq_count_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
                                                            RqBracket* br, unsigned int* hist, int sub_bits, int max_q, double* cand,
-                                                           unsigned int cand_cap) {
+                                                           unsigned int cand_cap, int skip_lut_rows) {
     constexpr int kWaveStage = kRqWaveStage;             // candidates a wave collects in LDS before it appends them
     __shared__ unsigned long long bound[P];
     __shared__ int shl[P / 2];
@@ -599,6 +664,7 @@ __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))
     RqBracket& B = br[row];
     const int nb = B.n_intervals;
     if (B.fallback || 2 * nb >= P || nb > max_q) return;   // (the host picks P > 2 * n_q >= 2 * nb)
+    if (skip_lut_rows && B.lut_ok) return;                 // rq_slab_kernel takes this row
     const int bins = 1 << sub_bits;
     if (threadIdx.x < P) {
         const int b = threadIdx.x >> 1;
@@ -747,6 +813,204 @@ __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))
     flush();
 }
 
+// (4') THE pass over the slab for rows whose bounds fit the bucket table (B.lut_ok; the others take rq_count_kernel<P, true>).
+// Same counts, sub-histograms and candidate buffer as rq_count_kernel<P, true>, at about half its instructions per
+// element — the slab pass was VALU-bound (81 % busy at 5.0 TB/s, profiles/r02), not HBM-bound:
+//  * no key conversion and no binary search: an equal-width bucket grid in VALUE over the span of the row's bounds (2048
+//    buckets: one fma, one conversion, one clamp) yields, through a byte table in LDS, the number of bounds below the
+//    bucket; the at most two bounds INSIDE the bucket are compared directly (one 16-byte LDS read of the pair
+//    (bound[base], bound[base + 1]), two v_cmp_ge_f64 + add-with-carry).  The 4-level search cost 4 dependent LDS reads,
+//    4 64-bit compares and 4 selects per element, plus the key conversion;
+//  * NaNs are routed to a trash position (one compare + select) instead of a separate per-lane counter;
+//  * members of a bracket (~4 % of the entries) are only STAGED in the element loop (ballot + mbcnt slot, one LDS write
+//    under the exec mask); their sub-histogram tally runs when the wave's stage is flushed, on full lanes — in the
+//    element loop that code ran for the whole wave whenever ANY lane held a member, i.e. nearly always.
+#ifndef MCR_RQ_UNROLL
+#define MCR_RQ_UNROLL 4
+#endif
+template <int P>
+__global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void rq_slab_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
+                                                          RqBracket* br, unsigned int* hist, int sub_bits, int max_q, double* cand,
+                                                          unsigned int cand_cap) {
+    constexpr int kStage = 192;                          // candidates a wave stages in LDS between two flushes
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    __shared__ unsigned long long bound[P];              // key bounds (sub-bin arithmetic of the staged candidates)
+    __shared__ __align__(16) d2_t pairs[P + 1];          // (value of bound i, value of bound i + 1), NaN-padded
+    __shared__ int bbucket[P];
+    __shared__ int shl[P / 2];
+    __shared__ double xlo_s[P / 2], invw_s[P / 2];
+    __shared__ unsigned char lut[kRqLutSize + 4];
+    // dynamic LDS: stage f64 [4][kStage] | poshist u32 [2 max_q + 2][256] | subhist u32 [max_q][2^sub_bits]
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    double* stage = reinterpret_cast<double*>(dyn_lds);
+    unsigned int* poshist = reinterpret_cast<unsigned int*>(dyn_lds + (kRqBlock / 64) * kStage * sizeof(double));
+    unsigned int* subhist = poshist + (size_t)(2 * max_q + 2) * kRqBlock;
+    const int row = blockIdx.y;
+    RqBracket& B = br[row];
+    const int nb = B.n_intervals;
+    if (B.fallback || !B.lut_ok || 2 * nb >= P || nb > max_q) return;
+    const int bins = 1 << sub_bits;
+    const double lut_s = B.lut_s;
+    double lut_c = B.lut_c;
+    asm volatile("" : "+v"(lut_c));                      // fma(x, s, c): one scalar operand at most — keep the addend in a VGPR
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (threadIdx.x < P) {
+        const int b = threadIdx.x >> 1;
+        const unsigned long long kb = b < nb ? ((threadIdx.x & 1) ? B.hi[b] + 1ull : B.lo[b]) : ~0ull;
+        bound[threadIdx.x] = kb;
+        const double bv = b < nb ? rq_bound_value(kb) : nan;
+        reinterpret_cast<double*>(pairs)[2 * threadIdx.x] = bv;
+        if (threadIdx.x > 0) reinterpret_cast<double*>(pairs)[2 * threadIdx.x - 1] = bv;
+        bbucket[threadIdx.x] = rq_lut_bucket_of_bound(bv, lut_s, lut_c);
+        if ((threadIdx.x & 1) == 0) { shl[b] = b < nb ? B.shift[b] : 0; xlo_s[b] = b < nb ? B.xlo[b] : 0.0; invw_s[b] = b < nb ? B.inv_w[b] : 0.0; }
+    }
+    if (threadIdx.x == 0) { reinterpret_cast<double*>(pairs)[2 * P - 1] = nan; reinterpret_cast<double*>(pairs)[2 * P] = nan; reinterpret_cast<double*>(pairs)[2 * P + 1] = nan; }
+    const int n_pos = 2 * nb + 2;                        // positions 0 .. 2 nb, then the trash position of the NaNs
+    const unsigned int trash = (unsigned int)(2 * nb + 1);
+    for (int k = threadIdx.x; k < n_pos * kRqBlock; k += kRqBlock) poshist[k] = 0u;
+    for (int k = threadIdx.x; k < nb * bins; k += kRqBlock) subhist[k] = 0u;
+    unsigned int keep = 0u;                              // bit p (odd p = 2b + 1): interval b is a real range: members are candidates
+    for (int b = 0; b < nb; ++b) keep |= (B.lo[b] < B.hi[b]) ? (1u << (2 * b + 1)) : 0u;
+    keep = (unsigned int)__builtin_amdgcn_readfirstlane((int)keep);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kRqLutSize; k += kRqBlock) {      // bounds in buckets below k
+        int c = 0;
+        for (int i = 0; i < 2 * nb; ++i) c += bbucket[i] < k ? 1 : 0;
+        lut[k] = (unsigned char)c;
+    }
+    __syncthreads();
+    const double* r = rows + (int64_t)row * row_stride;
+    double* crow = cand + (size_t)row * cand_cap;
+    const int lane = threadIdx.x & 63;
+    double* wstage = stage + (threadIdx.x >> 6) * kStage;      // this wave's stage; `filled` is wave-uniform
+    unsigned int filled = 0u;
+    unsigned int* myhist = poshist + threadIdx.x;
+
+    // position of x among the bounds (number of bounds <= x); NaN -> anything (the caller routes NaNs to the trash slot)
+    auto position = [&](double x) -> unsigned int {
+        const int k = rq_lut_bucket(x, lut_s, lut_c);
+        const unsigned int base = lut[k];
+        const d2_t bp = pairs[base];
+        return base + (x >= bp.x ? 1u : 0u) + (x >= bp.y ? 1u : 0u);
+    };
+    // sub-histogram tally of ONE member of interval b (full lanes at a flush; under the exec mask in the rare direct path)
+    auto tally_in = [&](double x, unsigned int b) {
+        atomicAdd(&subhist[b * bins + (unsigned int)rq_sub_bin(key_of(x), x, bound[2 * b], shl[b], xlo_s[b], invw_s[b], bins)], 1u);
+    };
+    auto tally = [&](double x) { tally_in(x, position(x) >> 1); };
+    auto flush = [&]() {
+        if (filled == 0u) return;
+        unsigned int base = 0u;
+        if (lane == 0) base = atomicAdd(&B.cand_count, filled);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        for (unsigned int i = lane; i < filled; i += 64u) {
+            const double x = wstage[i] + 0.0;                   // -0.0 -> +0.0 (see rq_bound_value)
+            tally(x);
+            if (base + i < cand_cap) crow[base + i] = x;
+        }
+        filled = 0u;
+    };
+
+    auto consume = [&](auto kc, const double* xs, const bool* oks) {
+        constexpr int K = decltype(kc)::value;
+        unsigned long long mask[K];
+        unsigned int total = 0u;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const double x = xs[u];
+            unsigned int pos = position(x);
+            pos = x != x ? trash : pos;
+            if (oks[u]) atomicAdd(&myhist[pos * kRqBlock], 1u);            // own slot: ds_add_u32, no conflicts
+            mask[u] = __ballot(oks[u] && ((keep >> pos) & 1u));            // (trash is even or beyond the keep bits: never a member)
+            total += (unsigned int)__popcll(mask[u]);
+        }
+        if (total == 0u) return;
+        if (total > (unsigned int)kStage) {
+            // more than a stage of members in one batch (a wide interval / a giant tie straddling a bound): straight to the row's buffer
+            flush();
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                if (mask[u] == 0ull) continue;
+                unsigned int base = 0u;
+                if (lane == 0) base = atomicAdd(&B.cand_count, (unsigned int)__popcll(mask[u]));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if ((mask[u] >> lane) & 1ull) {
+                    const double x = xs[u] + 0.0;
+                    const unsigned int slot = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask[u], 0u));
+                    tally(x);
+                    if (slot < cand_cap) crow[slot] = x;
+                }
+            }
+            return;
+        }
+        if (filled + total > (unsigned int)kStage) flush();
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            if (mask[u] == 0ull) continue;                                  // wave-uniform
+            if ((mask[u] >> lane) & 1ull)
+                wstage[filled + __builtin_amdgcn_mbcnt_hi((unsigned int)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask[u], 0u))] = xs[u];
+            filled += (unsigned int)__popcll(mask[u]);
+        }
+    };
+
+    const int64_t step = (int64_t)gridDim.x * kRqBlock;
+    const bool vec2 = ((row_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+    if (vec2) {
+        const d2_t* r2 = reinterpret_cast<const d2_t*>(r);
+        const int64_t n_pairs = n / 2;
+        const int64_t trips = (n_pairs + step - 1) / step;
+        constexpr int kUnroll = MCR_RQ_UNROLL;     // 16-byte loads per lane and batch; the next batch is in flight while this one is consumed
+        d2_t v[kUnroll];
+        bool okv[kUnroll];
+        auto fetch = [&](int64_t t) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+#ifdef MCR_RQ_TILED   // a batch = ONE contiguous 16 KB tile of the row per workgroup (instead of kUnroll chunks a grid stride apart)
+                const int64_t i = t * step + ((int64_t)blockIdx.x * kUnroll + u) * kRqBlock + threadIdx.x;
+#else
+                const int64_t i = (t + u) * step + (int64_t)blockIdx.x * kRqBlock + threadIdx.x;
+#endif
+                okv[u] = i < n_pairs;
+                v[u] = okv[u] ? __builtin_nontemporal_load(&r2[i]) : d2_t{0.0, 0.0};
+            }
+        };
+        if (trips > 0) fetch(0);
+        for (int64_t t = 0; t < trips; t += kUnroll) {
+            double xs[2 * kUnroll];
+            bool oks[2 * kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) { xs[2 * u] = v[u].x; xs[2 * u + 1] = v[u].y; oks[2 * u] = oks[2 * u + 1] = okv[u]; }
+            if (t + kUnroll < trips) fetch(t + kUnroll);
+            consume(std::integral_constant<int, 2 * kUnroll>{}, xs, oks);
+        }
+        if ((n & 1) && blockIdx.x == 0) {
+            const double x1 = r[n - 1];
+            const bool ok1 = threadIdx.x == 0;
+            consume(std::integral_constant<int, 1>{}, &x1, &ok1);
+        }
+    } else {
+        const int64_t trips = (n + step - 1) / step;
+        for (int64_t t = 0; t < trips; ++t) {
+            const int64_t i = t * step + (int64_t)blockIdx.x * kRqBlock + threadIdx.x;
+            const bool ok1 = i < n;
+            const double x1 = ok1 ? r[i] : 0.0;
+            consume(std::integral_constant<int, 1>{}, &x1, &ok1);
+        }
+    }
+    flush();
+    __syncthreads();
+    // fold the per-thread histograms: one wave per position at a time, one global atomic per position and workgroup
+    for (int p = threadIdx.x >> 6; p < n_pos; p += kRqBlock / 64) {
+        unsigned int c = poshist[p * kRqBlock + lane] + poshist[p * kRqBlock + 64 + lane] +
+                         poshist[p * kRqBlock + 128 + lane] + poshist[p * kRqBlock + 192 + lane];
+        for (int off = 32; off > 0; off >>= 1) c += (unsigned int)__shfl_down((int)c, off, 64);
+        if (lane == 0 && c) atomicAdd(p == (int)trash ? &B.n_nan : &B.pos_count[p], (unsigned long long)c);
+    }
+    unsigned int* hrow = hist + (size_t)row * kRqMaxQ * kRqMaxSubBins;
+    for (int k = threadIdx.x; k < nb * bins; k += kRqBlock)
+        if (subhist[k]) atomicAdd(&hrow[(k >> sub_bits) * kRqMaxSubBins + (k & (bins - 1))], subhist[k]);
+}
+
 // One wave turns h[0 .. len) (LDS) into its inclusive prefix sums, in place.
 __device__ __forceinline__ void rq_wave_inclusive_scan(unsigned int* h, int len, int lane) {
     const int per = (len + 63) / 64;
@@ -776,12 +1040,13 @@ __device__ __forceinline__ int rq_upper_bound(const unsigned int* pre, int len, 
 // side of every quantile lie — in which sub-bin of which coarse interval; the edges of those sub-bins are key bounds
 // that contain the wanted order statistics of the WHOLE row with overwhelming probability (and exactness is checked
 // against the slab's own counts afterwards).  A row whose window leaves its coarse interval takes the radix route.
-__global__ __launch_bounds__(256) void rq_refine_kernel(int64_t m, const RqArgs args, const RqBracket* br1, const unsigned int* hist1,
-                                                       RqBracket* br2, unsigned int* hist2, int sub_bits2, unsigned int* gfill) {
-    extern __shared__ __align__(16) unsigned int pre[];   // [n_intervals][1024]: inclusive prefix sums of the sub-histograms
-    __shared__ unsigned long long below[kRqMaxQ], upto[kRqMaxQ], qlo[kRqMaxQ], qhi[kRqMaxQ];
-    __shared__ unsigned int miss;
-    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63;
+// (All 256 threads of one workgroup, for one row.  The counters of the sample pass are read with device-scope atomic loads:
+//  the caller may be the LAST workgroup of that very pass — the others' counts arrived through global atomics.)
+__device__ void rq_refine_row(int row, int64_t m, const RqArgs& args, const RqBracket* br1, const unsigned int* hist1,
+                              RqBracket* br2, unsigned int* hist2, int sub_bits2, unsigned int* gfill, unsigned int* pre, RqRefineShared& S) {
+    unsigned long long* below = S.below; unsigned long long* upto = S.upto; unsigned long long* qlo = S.qlo; unsigned long long* qhi = S.qhi;
+    unsigned int& miss = S.miss;
+    const int t = threadIdx.x, lane = t & 63;
     const RqBracket& B1 = br1[row];
     RqBracket& B2 = br2[row];
     unsigned int* h2 = hist2 + (size_t)row * kRqMaxQ * kRqMaxSubBins;
@@ -791,20 +1056,20 @@ __global__ __launch_bounds__(256) void rq_refine_kernel(int64_t m, const RqArgs 
     constexpr int bins = 1 << kRqCoarseSubBits;
     if (t == 0) miss = B1.fallback;
     const unsigned int* h1 = hist1 + (size_t)row * kRqMaxQ * kRqMaxSubBins;
-    for (int k = t; k < nb * bins; k += 256) pre[k] = h1[(k >> kRqCoarseSubBits) * kRqMaxSubBins + (k & (bins - 1))];
+    for (int k = t; k < nb * bins; k += 256) pre[k] = rq_ld_u32(&h1[(k >> kRqCoarseSubBits) * kRqMaxSubBins + (k & (bins - 1))]);
     __syncthreads();
     for (int b = t >> 6; b < nb; b += 4) rq_wave_inclusive_scan(pre + b * bins, bins, lane);
     if (t == 0) {
         unsigned long long run = 0ull;
         for (int b = 0; b < nb; ++b) {
-            run += B1.pos_count[2 * b]; below[b] = run;
-            run += B1.pos_count[2 * b + 1]; upto[b] = run;
+            run += rq_ld_u64(&B1.pos_count[2 * b]); below[b] = run;
+            run += rq_ld_u64(&B1.pos_count[2 * b + 1]); upto[b] = run;
         }
     }
     __syncthreads();
     unsigned long long mv;   // non-NaN entries of the sample (m <= 0: a sample pooled over ranks, its size is the sum of the counts)
-    if (m > 0) mv = (unsigned long long)m - B1.n_nan;
-    else { mv = 0ull; for (int k = 0; k <= 2 * nb; ++k) mv += B1.pos_count[k]; }
+    if (m > 0) mv = (unsigned long long)m - rq_ld_u64(&B1.n_nan);
+    else { mv = 0ull; for (int k = 0; k <= 2 * nb; ++k) mv += rq_ld_u64(&B1.pos_count[k]); }
     if (t < args.n_q && !miss) {
         if (mv < 1024ull) {
             miss = 1u;
@@ -861,6 +1126,13 @@ __global__ __launch_bounds__(256) void rq_refine_kernel(int64_t m, const RqArgs 
         if (miss) { rq_make_intervals(B2, qlo, qhi, 0, sub_bits2); B2.fallback = 1u; }
         else rq_make_intervals(B2, qlo, qhi, args.n_q, sub_bits2);
     }
+}
+// stand-alone form (rows sharded over ranks: the sample's counts are summed across ranks before the brackets are refined)
+__global__ __launch_bounds__(256) void rq_refine_kernel(int64_t m, const RqArgs args, const RqBracket* br1, const unsigned int* hist1,
+                                                       RqBracket* br2, unsigned int* hist2, int sub_bits2, unsigned int* gfill) {
+    extern __shared__ __align__(16) unsigned int pre[];   // [n_intervals][1024]: inclusive prefix sums of the sub-histograms
+    __shared__ RqRefineShared S;
+    rq_refine_row(blockIdx.x, m, args, br1, hist1, br2, hist2, sub_bits2, gfill, pre, S);
 }
 
 // (5) and (6) Per row, after the slab pass: the true ranks (NumPy `linear`, as rq_scan_kernel computes them) are
@@ -1037,7 +1309,7 @@ __global__ __launch_bounds__(1024) void rq_select_kernel(int64_t n, const RqArgs
                                                         int sub_bits, unsigned int cand_cap, unsigned int list_cap,
                                                         const unsigned long long* glist, const unsigned int* gfill, double* out,
                                                         unsigned long long* counts, unsigned int* row_fallback, unsigned int* fb_list,
-                                                        unsigned int* fb_count, const unsigned int* cand_total) {
+                                                        unsigned int* fb_count, const unsigned int* cand_total, int row0) {
     extern __shared__ __align__(16) unsigned char dyn[];     // pre u32 [kRqMaxQ][bins] | list u64 [list_cap]
     __shared__ RqResolved R;
     __shared__ unsigned int whist[kRqWaves * 256];
@@ -1055,7 +1327,8 @@ __global__ __launch_bounds__(1024) void rq_select_kernel(int64_t n, const RqArgs
     }
     __syncthreads();
     if (R.fb) {
-        if (t == 0) { B.fallback = 1u; row_fallback[row] = 1u; fb_list[atomicAdd(fb_count, 1u)] = (unsigned int)row; }
+        // (row0: the kernel may run on a GROUP of rows whose per-row arrays arrive shifted; the fallback list holds row ids of the whole call)
+        if (t == 0) { B.fallback = 1u; row_fallback[row] = 1u; fb_list[atomicAdd(fb_count, 1u)] = (unsigned int)(row0 + row); }
         return;
     }
     if (t == 0) { row_fallback[row] = 0u; if (counts) counts[row] = m; }
@@ -1392,6 +1665,8 @@ static void rq_opt_in_lds(int device) {
     (void)hipFuncSetAttribute((const void*)(rq_count_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     (void)hipFuncSetAttribute((const void*)(rq_count_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void*)(rq_count_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_slab_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)(rq_slab_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     (void)hipGetLastError();
     lds_opt_in_device = device;
 }
@@ -1402,16 +1677,27 @@ static void rq_count_pass(hipStream_t s, const double* rows, int64_t row_stride,
     const bool small_p = 2 * n_q < 16;                        // bound table: the next power of two above 2 * (intervals <= quantiles)
     // slab pass: ~4096 workgroups (1280 .. 16384 measured flat within 2 % at 136 rows x 1e7); sample pass: few per row — every workgroup flushes its sub-histograms
     // (up to 1024 bins per interval) with global atomics, and the sample is only 1/32 of the slab
-    const int per_row = compact ? (4096 / n_rows > 0 ? 4096 / n_rows : 1) : (1024 / n_rows > 1 ? 1024 / n_rows : 2);
+    int per_row = compact ? (4096 / n_rows > 0 ? 4096 / n_rows : 1) : (1024 / n_rows > 1 ? 1024 / n_rows : 2);
+    if (const char* e = std::getenv(compact ? "MCR_RQ_SLAB_WGS" : "MCR_RQ_SAMPLE_WGS")) { const int t = std::atoi(e); if (t > 0) per_row = t / n_rows > 0 ? t / n_rows : 1; }
     const int bx = grid_for(len > 0 ? len : 1, kRqBlock * 16, per_row);
     const dim3 grid(bx, n_rows), block(kRqBlock);
     const int max_q = n_q;
     const size_t lds = (compact ? (size_t)(kRqBlock / 64) * kRqWaveStage * sizeof(double) : 0) +
                        (size_t)(2 * max_q + 1) * kRqBlock * sizeof(unsigned int) + (size_t)max_q * ((size_t)1 << sub_bits) * sizeof(unsigned int);
-#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap)
+    // the slab pass: rows whose bounds fit the bucket table take rq_slab_kernel, the others the generic kernel (whose
+    // workgroups return at once for the rows they do not own, and vice versa).  MCR_RQ_SLAB_LUT=0 keeps everything generic.
+    static const bool use_lut = [] { const char* e = std::getenv("MCR_RQ_SLAB_LUT"); return !(e && e[0] == '0'); }();
+    const int skip = (compact && use_lut) ? 1 : 0;     // (the sample pass stays generic: most of ITS entries are bracket members, tallied in place either way; measured 103 vs 125 us)
+#define MCR_COUNT(P, C) hipLaunchKernelGGL((rq_count_kernel<P, C>), grid, block, lds, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap, skip)
     if (small_p) { if (compact) MCR_COUNT(16, true); else MCR_COUNT(16, false); }
     else { if (compact) MCR_COUNT(32, true); else MCR_COUNT(32, false); }
 #undef MCR_COUNT
+    if (skip) {
+        const size_t lds2 = (size_t)(kRqBlock / 64) * 192 * sizeof(double) + (size_t)(2 * max_q + 2) * kRqBlock * sizeof(unsigned int) +
+                            (size_t)max_q * ((size_t)1 << sub_bits) * sizeof(unsigned int);
+        if (small_p) hipLaunchKernelGGL((rq_slab_kernel<16>), grid, block, lds2, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap);
+        else hipLaunchKernelGGL((rq_slab_kernel<32>), grid, block, lds2, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap);
+    }
 }
 
 }  // namespace mcr
@@ -1568,41 +1854,57 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     a.n_q = n_q;
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
     rq_opt_in_lds(device);
-    // (1) coarse brackets from the first kRqTiny entries of every row, sorted in LDS (paths are exchangeable; an
-    //     unlucky or adversarial prefix only costs the affected rows the fallback below)
-    hipLaunchKernelGGL(rq_tiny_kernel, dim3(n_rows), dim3(1024), 0, s, rows, row_stride, n, a, L.br1, L.hist1, L.fb_count);
-    // (2) the counting pass over a sample (the first n/32 entries), (3) fine brackets from its counts
-    int64_t m = n / 32;
+    int64_t m = n / 32;           // the second sample: the first n/32 entries of every row
     if (m < 65536) m = 65536;
     if (m > n) m = n;
     m &= ~(int64_t)1;
     const int sub_bits2 = n <= ((int64_t)1 << 24) ? 8 : 10;   // cells of a few hundred keys either way
     const unsigned int bcap = rq_bracket_cand_cap(n);
-    auto count_pass = [&](int64_t len, RqBracket* br, unsigned int* hist, int sub_bits, bool compact) {
-        rq_count_pass(s, rows, row_stride, n_rows, len, br, hist, sub_bits, compact, n_q, L.bcand, bcap);
+    const size_t bins = (size_t)1 << sub_bits2;
+    const unsigned int list_cap = sub_bits2 == 8 ? kRqListCap : kRqListCap / 2;
+    int collect_per_row = n >= ((int64_t)1 << 23) ? 4 : (n >= ((int64_t)1 << 21) ? 4 : 2);   // a few MB of candidates per row
+    if (const char* e = std::getenv("MCR_RQ_COLLECT_PER_ROW")) { const int t = std::atoi(e); if (t > 0) collect_per_row = t; }
+    const size_t hrow = (size_t)kRqMaxQ * kRqMaxSubBins;
+    // The six stages for rows [r0, r0 + nr) on stream `st` (every per-row array shifted to the group's first row).
+    auto head = [&](hipStream_t st, int r0, int nr, unsigned int* fb_reset) {
+        const double* rg = rows + (int64_t)r0 * row_stride;
+        // (1) coarse brackets from the first kRqTiny entries of every row, sorted in LDS (paths are exchangeable; an
+        //     unlucky or adversarial prefix only costs the affected rows the fallback below)
+        hipLaunchKernelGGL(rq_tiny_kernel, dim3(nr), dim3(1024), 0, st, rg, row_stride, n, a, L.br1 + r0, L.hist1 + r0 * hrow, fb_reset);
+        // (2) the counting pass over the sample, (3) fine brackets from its counts
+        //     (measured and dropped, round 3: letting the LAST workgroup of each row's sample pass refine that row on the spot
+        //      — one launch less — made the pass 120 us slower than pass + refine kernel: the fused kernel needs scratch memory)
+        rq_count_pass(st, rg, row_stride, nr, m, L.br1 + r0, L.hist1 + r0 * hrow, kRqCoarseSubBits, false, n_q, L.bcand + (size_t)r0 * bcap, bcap);
+        hipLaunchKernelGGL(rq_refine_kernel, dim3(nr), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), st, m, a, L.br1 + r0,
+                           L.hist1 + r0 * hrow, L.br2 + r0, L.hist2 + r0 * hrow, sub_bits2, L.gfill + (size_t)r0 * kRqMaxT);
     };
-    count_pass(m, L.br1, L.hist1, kRqCoarseSubBits, false);
-    hipLaunchKernelGGL(rq_refine_kernel, dim3(n_rows), dim3(256), (size_t)kRqMaxQ * kRqMaxSubBins * sizeof(unsigned int), s, m, a, L.br1,
-                       L.hist1, L.br2, L.hist2, sub_bits2, L.gfill);
-    // (4) the one pass over the slab
-    count_pass(n, L.br2, L.hist2, sub_bits2, true);
-    // (5) ranks -> cells; the candidates of the wanted cells; (6) selection in LDS -> interpolation
-    {
-        const size_t bins = (size_t)1 << sub_bits2;
-        const unsigned int list_cap = sub_bits2 == 8 ? kRqListCap : kRqListCap / 2;
-        const int per_row = n >= ((int64_t)1 << 23) ? 8 : (n >= ((int64_t)1 << 21) ? 4 : 2);   // a few MB of candidates per row
-        hipLaunchKernelGGL(rq_collect_kernel, dim3(per_row, n_rows), dim3(1024), (size_t)kRqMaxQ * bins * 5, s, n, a, L.br2, L.hist2, sub_bits2,
-                           L.bcand, bcap, list_cap, L.glist, L.gfill, (const unsigned int*)nullptr, (const unsigned int*)nullptr, 0, (int)n_rows);
+    auto slab = [&](hipStream_t st, int r0, int nr) {   // (4) the one pass over the slab
+        rq_count_pass(st, rows + (int64_t)r0 * row_stride, row_stride, nr, n, L.br2 + r0, L.hist2 + r0 * hrow, sub_bits2, true, n_q,
+                      L.bcand + (size_t)r0 * bcap, bcap);
+    };
+    auto tail = [&](hipStream_t st, int r0, int nr) {   // (5) ranks -> cells; the candidates of the wanted cells; (6) selection in LDS -> interpolation
+        hipLaunchKernelGGL(rq_collect_kernel, dim3(collect_per_row, nr), dim3(1024), (size_t)kRqMaxQ * bins * 5, st, n, a, L.br2 + r0, L.hist2 + r0 * hrow,
+                           sub_bits2, L.bcand + (size_t)r0 * bcap, bcap, list_cap, L.glist + (size_t)r0 * list_cap, L.gfill + (size_t)r0 * kRqMaxT,
+                           (const unsigned int*)nullptr, (const unsigned int*)nullptr, 0, nr);
         const size_t lds = (size_t)kRqMaxQ * bins * sizeof(unsigned int) + (size_t)list_cap * sizeof(unsigned long long);
-        hipLaunchKernelGGL(rq_select_kernel, dim3(n_rows), dim3(1024), lds, s, n, a, L.br2, L.hist2, sub_bits2, bcap, list_cap, L.glist, L.gfill,
-                           out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count, (const unsigned int*)nullptr);
-    }
+        hipLaunchKernelGGL(rq_select_kernel, dim3(nr), dim3(1024), lds, st, n, a, L.br2 + r0, L.hist2 + r0 * hrow, sub_bits2, bcap, list_cap,
+                           L.glist + (size_t)r0 * list_cap, L.gfill + (size_t)r0 * kRqMaxT, out + (size_t)r0 * n_q,
+                           counts ? (unsigned long long*)counts + r0 : nullptr, L.row_fallback + r0, L.fb_list, L.fb_count, (const unsigned int*)nullptr, r0);
+    };
+    // (Measured and dropped, round 3: cutting the rows into G groups on G streams, chained so that group g's slab pass starts
+    //  when group g - 1's ends and the latency-bound kernels of the neighbouring groups run under it.  136 rows x 1e7, A/B in
+    //  one process: G = 1 2.262 ms, G = 2 2.345, G = 3 2.478, G = 4 2.717 — cross-stream event waits cost more than the
+    //  0.35 ms of small kernels they were meant to hide.)
+    hipError_t e = hipSuccess;
+    head(s, 0, n_rows, L.fb_count);
+    slab(s, 0, n_rows);
+    tail(s, 0, n_rows);
     // (6) rows the brackets could not decide (a target outside its bracket, candidates overflowing on a wide tie
     //     that straddles a bracket end, a sample without data) take the full passes.  How many is only known on the
     //     device: this route reads one word back (ONE stream synchronisation per call) rather than launch eight
     //     passes of idle workgroups.
     unsigned int n_fb = 0;
-    hipError_t e = hipMemcpyAsync(&n_fb, L.fb_count, sizeof(n_fb), hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(&n_fb, L.fb_count, sizeof(n_fb), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return hip_fail(e, "bracketed row quantiles");
     g_last_fallback_rows = (int)n_fb;
@@ -1634,7 +1936,7 @@ int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_
         set_error("bad arguments");
         return MCR_ERR_INVALID_ARG;
     }
-    if (2 * n_q >= 32 || n_total < kRqTiny || (rank == 0 && n_local < kRqTiny)) {
+    if (2 * n_q >= 32 || n_total < kRqTiny) {   // (identical arguments on every rank: every rank returns here together)
         set_error("shape not supported by the sharded bracketed route (use the stepwise radix select)");
         return MCR_ERR_UNSUPPORTED;
     }
@@ -1642,6 +1944,25 @@ int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_
         if (!(q[j] >= 0.0 && q[j] <= 1.0)) { set_error("quantile %d out of [0,1]", j); return MCR_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)hip_stream;
     const RqLayout L = rq_layout(scratch, n_rows, n_local);
+    // Eligibility that depends on ONE rank's shard (rank 0 must hold the first sample) is decided COLLECTIVELY: every rank
+    // contributes a flag to the first reduction and all of them leave together — a rank that returned on its own would
+    // leave its peers waiting inside the caller's all-reduce.
+    {
+        const unsigned int mine = (rank == 0 && n_local < kRqTiny) ? 1u : 0u;
+        unsigned int total = 0u;
+        hipError_t e0 = hipMemcpyAsync(L.fb_count, &mine, sizeof(mine), hipMemcpyHostToDevice, s);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);       // (`mine` is a stack variable)
+        if (e0 != hipSuccess) return hip_fail(e0, "sharded quantiles (eligibility)");
+        if (reduce(reduce_ctx, L.fb_count, 1, MCR_DT_I32) != 0) { set_error("reduce callback failed (eligibility)"); return MCR_ERR_HIP; }
+        e0 = hipMemcpyAsync(&total, L.fb_count, sizeof(total), hipMemcpyDeviceToHost, s);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
+        if (e0 != hipSuccess) return hip_fail(e0, "sharded quantiles (eligibility)");
+        if (total != 0u) {
+            set_error("rank 0 holds fewer than %d entries of each row: the sharded bracketed route needs its first sample there "
+                      "(every rank returns this together; use the stepwise radix select)", kRqTiny);
+            return MCR_ERR_UNSUPPORTED;
+        }
+    }
     RqArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_q = n_q;
@@ -1700,7 +2021,7 @@ int mcr_row_quantiles_sharded(const double* rows, int64_t row_stride, int32_t n_
     // (6) selection in LDS -> interpolation (every rank computes the same)
     const size_t lds = (size_t)kRqMaxQ * bins * sizeof(unsigned int) + (size_t)list_cap * sizeof(unsigned long long);
     hipLaunchKernelGGL(rq_select_kernel, dim3(n_rows), dim3(1024), lds, s, n_total, a, L.br2, L.hist2, sub_bits2, bcap, list_cap, L.glist, L.gfill,
-                       out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count, L.cand_total);
+                       out, (unsigned long long*)counts, L.row_fallback, L.fb_list, L.fb_count, L.cand_total, 0);
     unsigned int n_fb = 0;
     e = hipMemcpyAsync(&n_fb, L.fb_count, sizeof(n_fb), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

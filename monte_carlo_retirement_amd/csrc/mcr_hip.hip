@@ -638,6 +638,56 @@ hipError_t host_ctx_reserve(HostCtx* c, size_t bytes) {
     return e;
 }
 
+// Fork/join streams (mcr_host.h: StreamFork): a few non-blocking side streams + events, leased from a process-wide pool
+// keyed by device for the duration of ONE call's enqueue (like HostCtx).  A lease only has to cover the host-side
+// enqueue: the side streams are in-order, and a stream that waits on an event waits for the record that preceded the
+// wait call, so the next lessee's records cannot disturb work that is still running.  Users: mcr_probe_months_rng
+// (candidates forked onto side streams) and mcr_row_quantiles (row groups pipelined against each other).
+static std::vector<StreamFork*> g_idle_fork;   // guarded by g_pool_mu
+constexpr int kStreamForkIdlePerDevice = 2;
+
+static void stream_fork_destroy(StreamFork* f) {   // pending work on a destroyed stream still completes (stream-ordered release)
+    for (int i = 0; i < kForkStreams; ++i) {
+        if (f->done[i]) (void)hipEventDestroy(f->done[i]);
+        if (f->side[i]) (void)hipStreamDestroy(f->side[i]);
+    }
+    if (f->fork) (void)hipEventDestroy(f->fork);
+    delete f;
+}
+StreamFork* stream_fork_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (size_t i = g_idle_fork.size(); i-- > 0;)
+            if (g_idle_fork[i]->device == device) {
+                StreamFork* f = g_idle_fork[i];
+                g_idle_fork.erase(g_idle_fork.begin() + (long)i);
+                return f;
+            }
+    }
+    StreamFork* f = new StreamFork();
+    std::memset(f, 0, sizeof(*f));
+    f->device = device;
+    bool ok = hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < kForkStreams; ++i)
+        ok = hipStreamCreateWithFlags(&f->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&f->done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); stream_fork_destroy(f); return nullptr; }
+    return f;
+}
+void stream_fork_release(StreamFork* f) {
+    StreamFork* surplus = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_idle_fork.push_back(f);
+        int same = 0;
+        for (StreamFork* o : g_idle_fork) same += o->device == f->device;
+        if (same > kStreamForkIdlePerDevice)
+            for (size_t i = 0; i < g_idle_fork.size(); ++i)
+                if (g_idle_fork[i]->device == f->device) { surplus = g_idle_fork[i]; g_idle_fork.erase(g_idle_fork.begin() + (long)i); break; }
+    }
+    if (surplus) stream_fork_destroy(surplus);
+}
+
 // Preconditions of the path kernel (its STRICT = false forms drop clamps that are no-ops only for rates and
 // weights in [0, 1] and non-negative amounts; fexp needs |x| < 700).  The reference enforces the same ranges
 // in its pydantic Config (backend/config.py:56-99); a ctypes caller that bypasses Config gets an error here,
@@ -907,71 +957,6 @@ int mcr_run_batch_rng(const mcr_params* p, const mcr_rng* rng, uint32_t stream_i
                         (hipStream_t)hip_stream);
 }
 
-// Fork/join helper for mcr_probe_months_rng: a few non-blocking side streams, leased from a process-wide pool keyed by
-// device for the duration of ONE call's enqueue (like HostCtx).  A lease only has to cover the host-side enqueue: the
-// side streams are in-order, and a stream that waits on an event waits for the record that preceded the wait call, so
-// the next lessee's records cannot disturb work that is still running.
-namespace {
-constexpr int kProbeStreams = 8;
-constexpr int kProbeForkIdlePerDevice = 2;
-struct ProbeFork {
-    int device;
-    hipStream_t side[kProbeStreams];
-    hipEvent_t done[kProbeStreams];
-    hipEvent_t fork;
-};
-std::vector<ProbeFork*> g_idle_fork;   // guarded by g_pool_mu
-
-void probe_fork_destroy(ProbeFork* f) {   // pending work on a destroyed stream still completes (stream-ordered release)
-    for (int i = 0; i < kProbeStreams; ++i) {
-        if (f->done[i]) (void)hipEventDestroy(f->done[i]);
-        if (f->side[i]) (void)hipStreamDestroy(f->side[i]);
-    }
-    if (f->fork) (void)hipEventDestroy(f->fork);
-    delete f;
-}
-ProbeFork* probe_fork_acquire(int device) {
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mu);
-        for (size_t i = g_idle_fork.size(); i-- > 0;)
-            if (g_idle_fork[i]->device == device) {
-                ProbeFork* f = g_idle_fork[i];
-                g_idle_fork.erase(g_idle_fork.begin() + (long)i);
-                return f;
-            }
-    }
-    ProbeFork* f = new ProbeFork();
-    std::memset(f, 0, sizeof(*f));
-    f->device = device;
-    bool ok = hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; ok && i < kProbeStreams; ++i)
-        ok = hipStreamCreateWithFlags(&f->side[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&f->done[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); probe_fork_destroy(f); return nullptr; }
-    return f;
-}
-void probe_fork_release(ProbeFork* f) {
-    ProbeFork* surplus = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mu);
-        g_idle_fork.push_back(f);
-        int same = 0;
-        for (ProbeFork* o : g_idle_fork) same += o->device == f->device;
-        if (same > kProbeForkIdlePerDevice)
-            for (size_t i = 0; i < g_idle_fork.size(); ++i)
-                if (g_idle_fork[i]->device == f->device) { surplus = g_idle_fork[i]; g_idle_fork.erase(g_idle_fork.begin() + (long)i); break; }
-    }
-    if (surplus) probe_fork_destroy(surplus);
-}
-struct ProbeForkLease {
-    explicit ProbeForkLease(int device) : f(probe_fork_acquire(device)) {}
-    ProbeForkLease(const ProbeForkLease&) = delete;
-    ProbeForkLease& operator=(const ProbeForkLease&) = delete;
-    ~ProbeForkLease() { if (f) probe_fork_release(f); }
-    ProbeFork* f;
-};
-}  // namespace
-
 // Several candidates over the same paths, Philox stream: ONE accumulation sweep to the largest candidate that stores the
 // state at the end of every candidate month (PHASE 1), then ONE launch whose grid.y is the candidate and which resumes
 // every decumulation from its snapshot (PHASE 2).  The candidates' parameter blocks (stream start months, horizon) go to
@@ -1057,10 +1042,10 @@ int mcr_probe_months_rng(const mcr_params* p, const mcr_rng* rng, uint32_t strea
         const int prc = probe_shared_prefix(p, rng, stream_id, path_begin, n_paths, working_months, n_candidates, counts, main);
         if (prc != MCR_ERR_UNSUPPORTED) return prc;     // (unsupported shape / allocation refused: one launch per candidate below)
     }
-    ProbeForkLease fork_lease(device);
-    ProbeFork* f = fork_lease.f;
+    StreamForkLease fork_lease(device);
+    StreamFork* f = fork_lease.f;
     if (!f) { set_error("could not create probe streams"); return MCR_ERR_HIP; }
-    const int used = n_candidates < kProbeStreams ? n_candidates : kProbeStreams;
+    const int used = n_candidates < kForkStreams ? n_candidates : kForkStreams;
     if ((e = hipEventRecord(f->fork, main)) != hipSuccess) return hip_fail(e, "probe fork");
     for (int i = 0; i < used; ++i)
         if ((e = hipStreamWaitEvent(f->side[i], f->fork, 0)) != hipSuccess) return hip_fail(e, "probe fork wait");
@@ -1270,7 +1255,7 @@ int mcr_validate_params(const mcr_params* p) { return validate_params(p); }
 
 int mcr_release_cached(int device) {
     std::vector<HostCtx*> ctxs;
-    std::vector<ProbeFork*> forks;
+    std::vector<StreamFork*> forks;
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
         for (size_t i = g_idle_ctx.size(); i-- > 0;)
@@ -1284,10 +1269,10 @@ int mcr_release_cached(int device) {
         if (scope.rc != MCR_OK) rc = scope.rc;   // (device gone: drop the bookkeeping anyway)
         host_ctx_destroy(c);
     }
-    for (ProbeFork* f : forks) {
+    for (StreamFork* f : forks) {
         DeviceScope scope(f->device);
         if (scope.rc != MCR_OK) rc = scope.rc;
-        probe_fork_destroy(f);
+        stream_fork_destroy(f);
     }
     return rc;
 }

@@ -87,4 +87,26 @@ public:
     HostCtx* ctx;
 };
 
+// Fork/join streams for calls that spread independent pieces of work over several HIP streams and join them back onto
+// the caller's stream: kForkStreams non-blocking side streams with one "done" event each, and a fork event.  Leased from
+// a process-wide pool keyed by device (mcr_hip.hip) for the duration of the call's ENQUEUE; at most 2 idle sets per
+// device stay cached (mcr_release_cached frees them).
+constexpr int kForkStreams = 8;
+struct StreamFork {
+    int device;
+    hipStream_t side[kForkStreams];
+    hipEvent_t done[kForkStreams];
+    hipEvent_t fork;
+};
+StreamFork* stream_fork_acquire(int device);         // nullptr on failure (out of resources)
+void stream_fork_release(StreamFork* f);
+class StreamForkLease {
+public:
+    explicit StreamForkLease(int device) : f(stream_fork_acquire(device)) {}
+    StreamForkLease(const StreamForkLease&) = delete;
+    StreamForkLease& operator=(const StreamForkLease&) = delete;
+    ~StreamForkLease() { if (f) stream_fork_release(f); }
+    StreamFork* f;
+};
+
 }  // namespace mcr

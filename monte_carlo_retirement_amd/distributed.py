@@ -17,6 +17,8 @@ exchange is the all-gather of the 49 B/path summary when a caller wants the per-
 
 from __future__ import annotations
 
+import contextlib
+import threading
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional, Tuple
 
@@ -33,8 +35,28 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, min(per, n_total - begin)
 
 
+_local = threading.local()
+
+
+@contextlib.contextmanager
+def local_only():
+    """Inside this block the calling thread computes as if no process group existed: every layer that shards
+    transparently (`run_monte_carlo_simulations`, the search's probes, `compact_result`) runs its single-GPU route.
+    For cross-checks — e.g. `bench.py` verifies that the candidate-split search replays the single-GPU search
+    probe for probe.  Every rank must enter/leave such a block at the same point of its program."""
+    prev = getattr(_local, "off", False)
+    _local.off = True
+    try:
+        yield
+    finally:
+        _local.off = prev
+
+
 def is_active() -> bool:
-    """True when a torch.distributed process group with more than one rank is initialised."""
+    """True when a torch.distributed process group with more than one rank is initialised (and the calling thread
+    is not inside :func:`local_only`)."""
+    if getattr(_local, "off", False):
+        return False
     try:
         import torch.distributed as dist
     except Exception:  # pragma: no cover

@@ -187,7 +187,11 @@ def compact_result(config: Config, simulator: RetirementMonteCarloSimulator, req
     if sharded:
         import torch.distributed as dist
 
-        begin, count = D.shard_range(n, dist.get_rank(), dist.get_world_size())
+        world = dist.get_world_size()
+        if D.shard_range(n, world - 1, world)[1] <= 0:   # (ceil(n / world)-sized shards: the last ranks go empty for tiny n)
+            raise ValueError(f"compact_result under a process group: {n} paths leave a rank of {world} without a shard; "
+                             "run so small a batch inside distributed.local_only() instead")
+        begin, count = D.shard_range(n, dist.get_rank(), world)
     else:
         begin, count = 0, n
     batch = E.DeviceBatch(simulator._current_params(), wm, max(count, 1), want="full", device=dev)
@@ -214,25 +218,31 @@ def compact_result(config: Config, simulator: RetirementMonteCarloSimulator, req
     swr = float(sq[3, median])
     qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
     samples = real_samples = None
-    try:
-        picked = np.random.RandomState(simulator.main_seed).choice(n, size=min(n, 5), replace=False)
-        from .simulation import _gather_columns
+    from .simulation import _gather_columns
 
+    # (only `choice` can raise — identically on every rank: same seed, same n; the collective below sits OUTSIDE the
+    #  try block and runs unconditionally, on a zero buffer when sampling failed, so the ranks cannot part ways here)
+    k = min(n, 5)
+    picked = None
+    try:
+        picked = np.random.RandomState(simulator.main_seed).choice(n, size=k, replace=False)
+    except ValueError as ve:     # e.g. main_seed >= 2**32: the reference logs and returns None (simulation.py:1079-1083)
+        logger.error(f"Error sampling trajectories: {ve}")
+    both = np.zeros((2, k, batch.sizes.trajectory_len))
+    if picked is not None:
         mine = [(j, int(g) - begin) for j, g in enumerate(picked) if begin <= g < begin + count]
-        both = np.zeros((2, len(picked), batch.sizes.trajectory_len))
         if mine:
             cols = [c for _, c in mine]
             both[0, [j for j, _ in mine]] = _gather_columns(batch.trajectory, cols)
             both[1, [j for j, _ in mine]] = _gather_columns(batch.real_trajectory, cols)
-        if sharded:   # owner ranks fill their columns, the rest stays 0: a sum is the gather
-            import torch
+    if sharded:   # owner ranks fill their columns, the rest stays 0: a sum is the gather
+        import torch
 
-            buf = torch.as_tensor(both, device=D._comm_device())
-            D.all_reduce_sum_(buf)
-            both = buf.cpu().numpy()
+        buf = torch.as_tensor(both, device=D._comm_device())
+        D.all_reduce_sum_(buf)
+        both = buf.cpu().numpy()
+    if picked is not None:
         samples, real_samples = both[0].tolist(), both[1].tolist()
-    except ValueError as ve:
-        logger.error(f"Error sampling trajectories: {ve}")
     years = trajectory_time_points(wm, config.retirement_years)
     bins, edges = A.success_histogram(batch.summary["final_balance"][:count], batch.success[:count], n_bins,
                                       reduce_range=D.all_reduce_minmax_ if sharded else None,

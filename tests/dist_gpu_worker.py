@@ -68,6 +68,21 @@ def main():
         np.array_equal(gb[r], np.quantile(big[r][~np.isnan(big[r])], A.TRAJECTORY_QUANTILES)) for r in range(4)))
     res["bracket_counts_equal"] = cb_.tolist() == (~np.isnan(big)).sum(axis=1).tolist()
     del blocal
+    # rows of exactly the DEFAULT threshold (2^18 entries in total, no override): the bracketed route must be the one taken
+    n_thr = A._SHARDED_BRACKET_MIN_TOTAL
+    rt = np.random.default_rng(11)
+    thr = np.stack([rt.lognormal(12, 1.5, n_thr), np.where(rt.random(n_thr) < 0.3, np.nan, rt.normal(0.0, 3.0, n_thr))])
+    t0, tc = D.shard_range(n_thr, rank, world)
+    tlocal = torch.full((2, (tc + 63) // 64 * 64), 7.0, dtype=torch.float64, device="cuda")
+    tlocal[:, :tc] = torch.as_tensor(thr[:, t0:t0 + tc], device="cuda")
+    gt, ct = D.sharded_row_quantiles(tlocal, tc, A.TRAJECTORY_QUANTILES)
+    res["bracket_at_threshold"] = bool(A.last_fallback_rows() >= 0 and ct.tolist() == (~np.isnan(thr)).sum(axis=1).tolist() and all(
+        np.array_equal(gt[r], np.quantile(thr[r][~np.isnan(thr[r])], A.TRAJECTORY_QUANTILES)) for r in range(2)))
+    gt2, _ = D.sharded_row_quantiles(tlocal[:, :tc - 40], tc - 40, A.TRAJECTORY_QUANTILES)      # just below it: the stepwise radix route
+    res["radix_below_threshold"] = bool(all(
+        np.array_equal(gt2[r], np.nanquantile(np.concatenate([thr[r, D.shard_range(n_thr, k, world)[0]:][:D.shard_range(n_thr, k, world)[1] - 40]
+                                                              for k in range(world)]), A.TRAJECTORY_QUANTILES)) for r in range(2)))
+    del tlocal
     os.environ["MCR_RQ_SHARDED_BRACKET_MIN_N"] = "100000"
     n_mid = 400_003
     rm = np.random.default_rng(9)

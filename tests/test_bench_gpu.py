@@ -27,29 +27,63 @@ def _run(*args, timeout=600):
 
 def test_bench_self_launches_two_ranks():
     n, steps = 200_000, 3
-    out = _run("--gpus", "2", "--backend", "gloo", "--steps", str(steps), "--warmup", "1", "--paths", str(n), "--s60-paths", "300001")
+    out = _run("--gpus", "2", "--backend", "gloo", "--steps", str(steps), "--warmup", "1", "--paths", str(n), "--s60-paths", "300001",
+               "--cpu-threads", "2", "--cpu-paths-per-thread", "4000", "--cpu-single-thread-paths", "4000")
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["unit"] == "paths/s"
     assert "all-reduce" in out["config"]["parallelism"] and "x2" in out["config"]["parallelism"]
     assert out["paths_counted"] == 2 * steps * n            # the exchange sums every rank's steps exactly once
     assert 0.9 < out["success_probability"] <= 1.0
     assert out["value"] == pytest.approx(2 * steps * n / (out["ms_per_step"] * 1e-3 * steps), rel=1e-6)
     assert out["roofline"]["bound"] == "valu_fp64" and 0.0 < out["roofline"]["frac"] < 1.0
-    s60 = out["s60"]
-    assert "error" not in s60, s60
-    assert s60["paths_counted"] == 300001 and s60["n_gpus"] == 2 and 0.5 < s60["success_probability"] < 1.0
-    assert s60["hist_total"] == round(s60["success_probability"] * 300001)
+    # what the process group contained: two ranks took part in a collective, each reports its device
+    c = out["config"]
+    assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and [d["rank"] for d in c["devices"]] == [0, 1]
+    assert all(d["gcn_arch"].startswith("gfx950") and d["compute_units"] == 256 for d in c["devices"])
+    for key in ("s60", "s60_data_ranged"):
+        s60 = out[key]
+        assert "error" not in s60, s60
+        assert s60["paths_counted"] == 300001 and s60["n_gpus"] == 2 and 0.5 < s60["success_probability"] < 1.0
+        assert s60["hist_total"] + s60["hist_outside_edges"] == round(s60["success_probability"] * 300001)
+    assert out["s60"]["exchange"].startswith("1 all-reduce(sum)")        # fixed edges: ONE collective
+    assert out["s60_data_ranged"]["hist_outside_edges"] == 0 and "min,max" in out["s60_data_ranged"]["exchange"]
+    assert out["s60"]["success_probability"] == out["s60_data_ranged"]["success_probability"]
+    # BASELINE configs[4]: the candidate-split search replays the single-GPU search probe for probe
+    sr = out["search"]
+    assert "error" not in sr, sr
+    assert sr["n_gpus"] == 2 and sr["equals_single_gpu_search"] is True and "by candidate" in sr["probe_split"]
+    assert sr["months_found"] == 232 and sr["probes"] == 17 and sr["paths_per_probe"] == 50_000
+    assert sr["final_run_paths"] == 1_000_000 and 90.0 < sr["final_success_probability_pct"] < 100.0
+    # rank 0 times the CPU baseline under N > 1 too
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["host_cores"] >= 1 and cb["single_thread"]["cores"] == 1
 
 
 def test_bench_single_gpu_line_has_the_contract_keys():
     out = _run("--steps", "3", "--warmup", "1", "--paths", "200000", "--aux-paths", "2200000", "--s60-paths", "400000",
-               "--cpu-threads", "4", "--cpu-paths-per-thread", "2000")
+               "--cpu-threads", "4", "--cpu-paths-per-thread", "2000", "--cpu-single-thread-paths", "2000")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "hbm_kernels", "s60"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "hbm_kernels", "s60", "s60_data_ranged", "search"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["dtype"] == "f64" and out["vs_baseline"] is None and out["paths_counted"] == 3 * 200000
-    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 4
-    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 4 and cb["value"] > cb["single_thread"]["value"] > 0
+    assert cb["host_cores"] >= cb["usable_cores"] >= 4 and isinstance(cb["cpu_model"], str) and cb["cpu_model"]
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_of_measured_issue_ceiling"}
     assert out["s60"]["paths_counted"] == 400000 and out["hbm_kernels"]["K3_row_quantiles"]["rows"] == 136
+    assert out["s60"]["exchange"] == "none (1 GPU)" and "inside the count-only path kernel" in out["s60"]["workload"]
+    assert out["s60"]["success_probability"] == out["s60_data_ranged"]["success_probability"]
+    c = out["config"]
+    assert c["ranks_seen"] == 1 and c["backend"] is None and len(c["devices"]) == 1 and c["devices"][0]["device_index"] == 0
+    # BASELINE configs[4] through the class API.  (The survey's reference run found 233 months on this scenario with its
+    # NumPy stream and 300 paths per probe; the engine's stream at 50 000 paths per probe: 232 months, 17 probes.  The
+    # search LOGIC is pinned against six searches recorded from the reference in tests/test_simulator_gpu.py.)
+    sr = out["search"]
+    assert "error" not in sr, sr
+    assert sr["months_found"] == 232 and sr["probability_pct"] == pytest.approx(97.184) and sr["probes"] == 17
+    assert sr["probe_rounds"] <= sr["probes"] and sr["months_evaluated"] >= sr["probes"]
+    assert sr["search_seconds"] > 0 and sr["ms_per_probe"] == pytest.approx(sr["search_seconds"] / sr["probes"] * 1e3)
+    assert sr["final_run_paths"] == 1_000_000 and 97.0 < sr["final_success_probability_pct"] < 99.5
+    assert "equals_single_gpu_search" not in sr                       # (only meaningful under a process group)
     acc = out["accuracy_10k"]      # BASELINE's "success-prob abs error vs CPU ref, 10k-path config"
     assert "error" not in acc, acc
     assert acc["abs_error"] <= 1e-4 and acc["flipped_success_flags"] == 0
@@ -69,6 +103,8 @@ def test_bench_group_code_path_over_rccl_with_one_rank():
     assert out["n_gpus"] == 1 and out["paths_counted"] == steps * n            # the last exchange holds the totals
     assert "all-reduce(sum)" in out["config"]["parallelism"] and "nccl" in out["config"]["parallelism"]
     assert "error" not in out["s60"] and out["s60"]["paths_counted"] == 300001
+    assert out["config"]["ranks_seen"] == 1 and out["config"]["backend"] == "nccl"
+    assert "error" not in out["search"] and out["search"]["months_found"] == 232
 
 
 def test_library_collectives_over_rccl_with_one_rank(tmp_path):
@@ -98,3 +134,15 @@ def test_library_collectives_over_rccl_with_one_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300))
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_launcher_deadline_kills_hung_ranks_and_reports(tmp_path):
+    """launch_ranks cannot wait forever: with a 1-second overall deadline the two children (still importing torch) are
+    killed by PID, the exit code is non-zero and the parent says which ranks it killed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MCR_BENCH_DEADLINE_S"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "200", "--paths", "4000000"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert "overall deadline reached" in r.stderr and "killing ranks [0, 1]" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

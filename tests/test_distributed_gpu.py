@@ -40,6 +40,7 @@ def test_sharded_quantiles_and_bands_equal_unsharded(tmp_path, world):
     for r in res:
         assert r["quantiles_equal"] and r["counts_equal"], r
         assert r["bracket_route_taken"] and r["bracket_quantiles_equal"] and r["bracket_counts_equal"], {k: v for k, v in r.items() if k.startswith("bracket")}
+        assert r["bracket_at_threshold"] and r["radix_below_threshold"], r
         assert r["bracket_mid_equal"] and r["bracket_mid_counts"] and 1 <= r["bracket_fallback_rows"] <= 5, {k: v for k, v in r.items() if k.startswith("bracket")}
         assert r["bracket_fallback_rows"] == res[0]["bracket_fallback_rows"]
         assert r["fuzz_bad"] == [] and r["fuzz_bracket_calls"] >= 1, (r["fuzz_bad"], r["fuzz_bracket_calls"])
