@@ -123,8 +123,11 @@ def aux_hbm_kernels(torch, n):
     b = E.DeviceBatch(p, 75, n, want="full")
     T, ry = b.sizes.trajectory_len, b.sizes.retirement_years
 
-    def timed(fn, reps=5):
-        fn()                              # first call: scratch allocation, cold caches
+    def timed(fn, reps=15, warm=3):
+        # steady state: after an idle gap the first calls of a ~2 ms kernel sequence run 10-20 % slow while the clocks ramp
+        # (tools/k3_series.py: 2.72, 2.61, 2.48, 2.44, 2.34, then 2.27 +- 0.01 ms); the first call also allocates scratch
+        for _ in range(warm):
+            fn()
         ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -293,6 +293,11 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
 #define MCR_HELPER_NLV2_PATH 12       /* in[4]=(b1,cb1,b2,cb2) out[2] */
 #define MCR_HELPER_REBALANCE_PATH 13  /* in[4]=(b1,cb1,b2,cb2) out[4] */
 #define MCR_HELPER_ANNUAL_TAX_PATH 14 /* in[6]=(b1,cb1,b2,cb2,g1,g2) out[5]=(b1,cb1,b2,cb2,tax_failed) */
+/* the PATH FORMS of the math (shorter series inside the month loop: their truncation errors are sized to the 1e-9 path
+ * tolerance instead of the last ulp — csrc/mcr_math.h; bounds measured in tests/test_gpu_math.py) */
+#define MCR_HELPER_MATH_EXP_PATH 15     /* in[1]=(x)            out[1]=exp(x), r^2/24 -> a^2/40 (|err| <= 3.5e-15, mean 0) */
+#define MCR_HELPER_MATH_NEG2LOG_PATH 16 /* in[1]=(x as uint32)  out[1]=-2 ln((x+0.5) 2^-32), series to r^4 (<= 3.6e-13 absolute) */
+#define MCR_HELPER_MATH_SINCOS_PATH 17  /* in[1]=(x as uint32)  out[2]=(sin, cos), cos series to dl^4 (<= 4.7e-15 absolute)  */
 /* Evaluates helper `which` ON THE DEVICE for n rows (host buffers, row-major). */
 int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out,
                          int64_t n, int device);

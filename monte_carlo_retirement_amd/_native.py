@@ -41,6 +41,9 @@ MCR_HELPER_WITHDRAW2_PATH = 11
 MCR_HELPER_NLV2_PATH = 12
 MCR_HELPER_REBALANCE_PATH = 13
 MCR_HELPER_ANNUAL_TAX_PATH = 14
+MCR_HELPER_MATH_EXP_PATH = 15
+MCR_HELPER_MATH_NEG2LOG_PATH = 16
+MCR_HELPER_MATH_SINCOS_PATH = 17
 _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_WITHDRAW: (5, 4),
     MCR_HELPER_NLV: (4, 1),
@@ -57,6 +60,9 @@ _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_NLV2_PATH: (4, 2),
     MCR_HELPER_REBALANCE_PATH: (4, 4),
     MCR_HELPER_ANNUAL_TAX_PATH: (6, 5),
+    MCR_HELPER_MATH_EXP_PATH: (1, 1),
+    MCR_HELPER_MATH_NEG2LOG_PATH: (1, 1),
+    MCR_HELPER_MATH_SINCOS_PATH: (1, 2),
 }
 
 

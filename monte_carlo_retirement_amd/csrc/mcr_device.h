@@ -111,8 +111,8 @@ __device__ __forceinline__ void bm_pair(uint32_t xr, uint32_t xa, const double* 
 // The same pair as its PARTS: radius r and the angle's (cos, sin), the two normals being r cos and r sin.  growth_rows2
 // folds the products into the log-returns instead of forming the normals first.
 __device__ __forceinline__ void bm_parts(uint32_t xr, uint32_t xa, const double* tab, const MathRegs& R, double& r, double& c, double& s) {
-    r = fsqrt(neg2_log_u32(xr, tab, R));
-    sincos_u32<true>(xa, tab, R, s, c);
+    r = fsqrt(neg2_log_u32<true>(xr, tab, R));      // path forms of the series (mcr_math.h)
+    sincos_u32<true, true>(xa, tab, R, s, c);
 }
 
 struct ShockGen {      // per-lane carry between consecutive rows
@@ -223,9 +223,9 @@ __device__ __forceinline__ void growth_rows2(const DevParams& P, const MathRegs&
         const double x_eq = fma_vvs(P.b1 * rad[je >> 1], trig[je], P.a1);
         const double x_inf = __builtin_fma(P.binf_rho * rad[je >> 1], trig[je], fma_vvs(P.binf_rho_c * rad[ji >> 1], trig[ji], P.ainf));
         const double x_prem = fma_vvs(P.bprem * rad[jp >> 1], trig[jp], P.aprem);
-        const double g1 = fexp(x_eq, tab, M);
-        const double ginf = fexp(x_inf, tab, M);
-        const double gprem = fexp(x_prem, tab, M);
+        const double g1 = fexp<true>(x_eq, tab, M);
+        const double ginf = fexp<true>(x_inf, tab, M);
+        const double gprem = fexp<true>(x_prem, tab, M);
         stage[(3 * r + 0) * kBlock] = g1;
         stage[(3 * r + 1) * kBlock] = ginf;
         stage[(3 * r + 2) * kBlock] = ginf * gprem;                             // :532

@@ -95,6 +95,15 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     constexpr bool kStaged = RNG == (int)MCR_RNG_PHILOX && !INJ;
     __shared__ __align__(16) double tab_s[kTabDoubles];
     __shared__ __align__(16) double stage_s[kStaged ? kStageDoubles : 1];
+    // Per-path values that are written once or twice in a lifetime and read at the very end (first-year withdrawals,
+    // YearsToRuin) live in the lane's own LDS column in the variants with per-path outputs: held to 5 waves per SIMD those
+    // variants had no registers for them (round 2: 12 / 36 bytes of scratch per lane, 4-12 VGPRs spilled).
+    // A/B on one box (tools/k1_modes_ab.py): summary output, 2e7 S60 paths 126.44 -> 126.23 ms; trajectories, 1e7 jorge paths
+    // 50.28 -> 50.07 ms, 4e6 config.json paths 29.59 -> 29.40 ms.  A fourth column (the start-of-retirement balance) frees the
+    // trajectory variant of its last 12 bytes of scratch but its 2 KB cost a resident workgroup as soon as the scenario has a
+    // non-indexed income stream (one more LDS column): 50.07 -> 52.2 ms on jorge.json.  Three it is.
+    constexpr bool kSumLds = MODE >= 1 && kStaged;
+    __shared__ __align__(16) double sum_s[kSumLds ? 3 * kBlock : 1];
     extern __shared__ __align__(16) unsigned char smem_raw[];
 #ifdef MCR_K1_TIMELINE   // diagnostic build only (tools/k1_timeline.py): per-wave start / end stamps and placement
     const unsigned long long tl_t0 = wall_clock64();
@@ -105,6 +114,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw, threadIdx.x, kBlock);
     // Philox stream: the gross factors of two months at a time, staged per lane (growth_rows2)
     double* stage = stage_s + (kStaged ? threadIdx.x : 0);
+    double* sum_col = sum_s + (kSumLds ? threadIdx.x : 0);     // [0] first-year gross, [kBlock] first-year real gross, [2 kBlock] YearsToRuin bits
     double* lock_lds = reinterpret_cast<double*>(smem_raw + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0));
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
     // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram; then the
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     // Top of every month (wave-uniform, outside any divergent region): rows are visited in order 0, 1, 2, ... across
     // both phases, so each pair of rows is generated exactly when its first row comes up.
     PairCarry carry{0u, 0u};
-    const MathRegs GR = kStaged ? MathRegs::pinned() : MathRegs::literals();
+    const MathRegs GR = kStaged ? MathRegs::pinned_path() : MathRegs::literals();
     // Wave priority falls as the path advances (s_setprio takes an immediate: four levels).  The SIMD arbitrates VALU
     // issue by priority, then age; left alone, the oldest wave of a SIMD runs far ahead and the youngest is left to
     // finish ALONE at the end of the launch, at a fraction of the SIMD's issue rate (measured with per-wave
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     bool alive = !pre_fail;                          // :627, :633
     bool succeeded = !pre_fail;
     unsigned long long ytr_bits = pre_fail ? f64_bits(0.0) : kNanBits;  // YearsToRuin (:497, :628-629)
+    if (kSumLds) { sum_col[0] = 0.0; sum_col[kBlock] = 0.0; store_bits(&sum_col[2 * kBlock], ytr_bits); }
     int ruin_bin = pre_fail ? 0 : -1;
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
@@ -328,10 +339,14 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
         if (alive) {
             const double ygw = tg1 + tg2;                                              // :830-832
             const double wr_pct = start_balance > kEps ? (treal / start_balance) * 100.0 : 0.0;  // :834-840
-            if (year == 0) { fy_gross = ygw; fy_real = treal; }                        // :852-856, :861-865
+            if (year == 0) {                                                           // :852-856, :861-865
+                if (kSumLds) { sum_col[0] = ygw; sum_col[kBlock] = treal; }
+                else { fy_gross = ygw; fy_real = treal; }
+            }
             if (yfail) {
                 succeeded = false;                                                     // :843
-                ytr_bits = f64_bits((double)(fail_rmi + 1) / (double)kMPY);            // :825-827, :844-847
+                if (kSumLds) sum_col[2 * kBlock] = (double)(fail_rmi + 1) / (double)kMPY;  // :825-827, :844-847
+                else ytr_bits = f64_bits((double)(fail_rmi + 1) / (double)kMPY);
                 ruin_bin = 1 + year;
                 sample = fmax(0.0, b1 + b2);                                           // :848
                 alive = false;                                                         // :857
@@ -354,13 +369,17 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
             const bool tf = annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
-            if (tf) { succeeded = false; ytr_bits = f64_bits((double)ry); ruin_bin = ry + 1; }  // :894-896
+            if (tf) {                                                            // :894-896
+                succeeded = false; ruin_bin = ry + 1;
+                if (kSumLds) sum_col[2 * kBlock] = (double)ry; else ytr_bits = f64_bits((double)ry);
+            }
             put_sample(P.trajectory_len - 1, b1 + b2, infl);                     // :897-898
         }
     }
     const double final_balance = fmax(0.0, b1 + b2);  // :900, :941
 
     // ---- outputs ----
+    if (kSumLds) { fy_gross = sum_col[0]; fy_real = sum_col[kBlock]; ytr_bits = f64_bits(sum_col[2 * kBlock]); }
     if (kSummary && valid) {
         const mcr_outputs& o = io.out;
         if (o.start_balance) o.start_balance[li] = start_balance;
@@ -514,6 +533,14 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
             break;
         }
         case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab, MathRegs::literals()); break;
+        case MCR_HELPER_MATH_EXP_PATH: out[i] = fexp<true>(in[i], tab, MathRegs::literals_path()); break;
+        case MCR_HELPER_MATH_NEG2LOG_PATH: out[i] = neg2_log_u32<true>((uint32_t)in[i], tab, MathRegs::literals_path()); break;
+        case MCR_HELPER_MATH_SINCOS_PATH: {
+            double sn, cs;
+            sincos_u32<true, true>((uint32_t)in[i], tab, MathRegs::literals_path(), sn, cs);
+            out[2 * i] = sn; out[2 * i + 1] = cs;
+            break;
+        }
         case MCR_HELPER_MATH_SINCOS: {
             double sn, cs;
             sincos_u32<true>((uint32_t)in[i], tab, MathRegs::literals(), sn, cs);
@@ -825,7 +852,7 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     return MCR_OK;
 }
 
-constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)kStageDoubles * sizeof(double);   // (upper bound over the variants)
+constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)(kStageDoubles + 3 * kBlock) * sizeof(double);   // (upper bound over the variants)
 static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng, int n_hist_bins = 0) {
     // the dynamic part only: the math tables and the stage of growth factors are static LDS of the kernel
     return (numpy_rng ? (size_t)kZigLdsBytes : (size_t)0) +
@@ -1342,6 +1369,9 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
         case MCR_HELPER_MATH_SQRT: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_NEG2LOG: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_SINCOS: n_in = 1; n_out = 2; break;
+        case MCR_HELPER_MATH_EXP_PATH: n_in = 1; n_out = 1; break;
+        case MCR_HELPER_MATH_NEG2LOG_PATH: n_in = 1; n_out = 1; break;
+        case MCR_HELPER_MATH_SINCOS_PATH: n_in = 1; n_out = 2; break;
         default: set_error("unknown helper %d", which); return MCR_ERR_INVALID_ARG;
     }
     if (!in || !out || n < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }

@@ -90,3 +90,40 @@ def test_sincos_absolute_error():
     ec = np.abs(got[:, 1].astype(np.longdouble) - np.cos(ang)).astype(np.float64)
     assert max(es.max(), ec.max()) < 3e-16, (es.max(), ec.max())
     assert np.abs(got[:, 0] ** 2 + got[:, 1] ** 2 - 1.0).max() < 5e-16
+
+
+def test_path_forms_of_the_series_stay_inside_their_stated_bounds():
+    """The month loop runs shorter series (template parameter PATH of csrc/mcr_math.h): their truncation errors are sized to
+    the 1e-9 PATH tolerance — what a growth factor may be off by is ~1e-9 / 833 months per month in the worst, one-signed
+    case — not to the last ulp.  Stated bounds, measured here on the device:
+      exp         relative error <= 3.5e-15 with ZERO MEAN (r^2/24 replaced by its mean-square fit a^2/40, a = ln 2 / 1024: the
+                  error r^4/24 - a^2 r^2/40 changes sign inside the reduction interval; a one-signed truncation would add
+                  up over 2040 months) on top of the full form's 2 ulp;
+      -2 ln u     absolute error <= 3.6e-13 (the dropped 2 r^5/5 - r^6/3, |r| <= 2^-8) on top of 2 ulp;
+      cos         absolute error <= 4.7e-15 (the dropped dl^6/720, |dl| <= pi/256) on top of 3e-16; sin as the full form.
+    Path-level effect (tools/k1_accuracy.py, 2e5 paths x 3 scenarios against the oracle): worst error 7e-11 of the 1e-9
+    allowed, no Success flag flipped."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-2, 2, 300_000), [0.0, 1e-300, 0.6931471805599453 / 1024, -0.6931471805599453 / 1024]])
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_EXP_PATH, None, x.reshape(-1, 1))[:, 0]
+    exact = np.exp(x.astype(np.longdouble))
+    rel = np.abs((got.astype(np.longdouble) - exact) / exact).astype(np.float64)
+    assert rel.max() <= 3.5e-15 + 2 * 2.2e-16, rel.max()
+    assert rel.max() > 1.5e-15                       # (the form under test really is the shorter one)
+    signed = ((got.astype(np.longdouble) - exact) / exact).astype(np.float64)[:300_000]
+    assert abs(signed.mean()) < 1.5e-16, signed.mean()   # zero mean: sqrt(months), not months, times the per-month error
+
+    u32 = np.concatenate([rng.integers(0, 2**32, 400_000), [0, 1, 2, 2**31, 2**32 - 1, 2**32 - 2]]).astype(np.float64)
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_NEG2LOG_PATH, None, u32.reshape(-1, 1))[:, 0]
+    u = (u32.astype(np.longdouble) + np.longdouble(0.5)) * np.longdouble(2.0) ** -32
+    err = np.abs(got.astype(np.longdouble) + 2 * np.log(u)).astype(np.float64)
+    assert np.all(err <= 3.6e-13 + 2.0 * np.spacing(got)), float(err.max())
+    assert err.max() > 1e-14 and np.all(got > 0)
+
+    got = E.eval_helper_host(N.MCR_HELPER_MATH_SINCOS_PATH, None, u32.reshape(-1, 1))
+    two_pi = np.longdouble("6.283185307179586476925286766559005768")
+    ang = (u32.astype(np.longdouble) + np.longdouble(0.5)) * two_pi / np.longdouble(2.0) ** 32
+    es = np.abs(got[:, 0].astype(np.longdouble) - np.sin(ang)).astype(np.float64)
+    ec = np.abs(got[:, 1].astype(np.longdouble) - np.cos(ang)).astype(np.float64)
+    assert es.max() < 3e-16 + 4.7e-15 and ec.max() < 3e-16 + 4.7e-15, (es.max(), ec.max())   # (the rotation mixes cos(dl) into both)
+    assert ec.max() > 1e-15
