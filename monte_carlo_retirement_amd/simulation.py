@@ -197,6 +197,11 @@ class RetirementMonteCarloSimulator:
         #: results, no communication): a 50 000-path probe is latency-bound (~1 ms) and sharding it would add
         #: an all-reduce + host sync per probe.  Larger batches are sharded across the ranks.
         self.shard_min_paths = 1_000_000
+        #: under torch.distributed, sharded batches of MORE paths than this deliver the per-path summary frame (n x 7: 56 bytes
+        #: a path, 5.6 GB at 1e8 paths) to rank 0 ONLY — the other ranks get a frame with the reference's columns and no rows —
+        #: instead of all-gathering it into the host memory of every rank.  Everything else of the 7-tuple (bands, sampled
+        #: paths, observation counts) is identical on all ranks either way; `results.compact_result` needs no per-path frame.
+        self.gather_all_max_paths = 20_000_000
         # NumPy stream bookkeeping: children spawned so far per stream, and the offset at which each
         # (stream, n) batch was spawned — the reference's _path_seed_cache rule (:154, :192-199)
         self._np_children_spawned = {"search": 0, "final": 0}
@@ -421,7 +426,8 @@ class RetirementMonteCarloSimulator:
     def _run_sharded(self, wm: int, n: int):
         """run_monte_carlo_simulations with one process per GPU (torch.distributed initialised): every rank
         simulates its shard of the global path range [0, n) and keeps its trajectories in its own HBM; the
-        per-path summary is all-gathered (49 B/path), the quantile bands come from the distributed radix
+        per-path summary is all-gathered (49 B/path; above `gather_all_max_paths` paths: gathered to rank 0 only,
+        the reference's `summary_df` contract being a single-process one, simulation.py:1012-1027), the quantile bands come from the distributed radix
         select (digit histograms summed across ranks), the sampled paths are contributed by the rank that
         owns them.  Every rank returns the same 7-tuple, bit-identical to the single-GPU result."""
         import torch
@@ -443,13 +449,25 @@ class RetirementMonteCarloSimulator:
                 local[i, :count] = batch.summary[f][:count]
             local[len(fields), :count] = batch.success[:count].to(torch.float64)
         local = local.to(comm)
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)
-        # trimmed and joined on the HOST (64-bit NumPy indexing whatever n is)
-        allf = np.concatenate([g[:, :D.shard_range(n, r, world)[1]].cpu().numpy() for r, g in enumerate(gathered)], axis=1)
-        cols = {name: allf[i] for i, name in enumerate(_FIELD_OF.keys())}
-        cols["Success"] = allf[len(fields)] != 0.0
-        summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
+        to_rank0_only = n > self.gather_all_max_paths
+        if to_rank0_only:
+            logger.warning(f"{n} paths over {world} ranks: the per-path summary frame goes to rank 0 only "
+                           f"(gather_all_max_paths = {self.gather_all_max_paths}); the other ranks return an empty frame")
+            gathered = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+            dist.gather(local, gathered, dst=0)
+        else:
+            gathered = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+        del local
+        if gathered is None:
+            summary_df = pd.DataFrame({c: pd.Series(dtype=bool if c == "Success" else np.float64) for c in SUMMARY_COLUMNS})
+        else:
+            # trimmed and joined on the HOST (64-bit NumPy indexing whatever n is)
+            allf = np.concatenate([g[:, :D.shard_range(n, r, world)[1]].cpu().numpy() for r, g in enumerate(gathered)], axis=1)
+            del gathered
+            cols = {name: allf[i] for i, name in enumerate(_FIELD_OF.keys())}
+            cols["Success"] = allf[len(fields)] != 0.0
+            summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
         # ---- bands ----
         traj_q, real_q, wr_q, wr_counts = D.sharded_band_quantiles(batch, count)
         qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")

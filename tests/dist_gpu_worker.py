@@ -206,6 +206,21 @@ def main():
     res["class_search_replays_reference"] = bool(
         s_res[0] == g["months"] and s_res[1] == g["probability"] and s_res[2] == g["search_curve"] and s_events == g["events"])
     res["class_search_batched"] = bool(len(s_calls) < len(g["search_curve"]))
+    # large-n guard: above gather_all_max_paths the per-path frame goes to rank 0 only; the rest of the tuple is unchanged
+    sim.shard_min_paths = 0
+    sim.use_final_seeds()
+    sim.gather_all_max_paths = 1000
+    guarded = sim.run_monte_carlo_simulations(wm, n_paths)
+    sim.gather_all_max_paths = 20_000_000
+    res["guard_frame_rows"] = int(len(guarded[0]))
+    res["guard_frame_columns_ok"] = list(guarded[0].columns) == list(summary.columns) and str(guarded[0]["Success"].dtype) == "bool"
+    res["guard_rank0_frame_equal"] = bool(rank != 0 or guarded[0].equals(summary))
+    res["guard_rest_equal"] = bool(np.array_equal(guarded[1].to_numpy(), tdf.to_numpy(), equal_nan=True) and guarded[2] == samples
+                                   and np.array_equal(guarded[3].to_numpy(), wdf.to_numpy(), equal_nan=True) and guarded[5] == rsamples
+                                   and guarded[6] == wcounts)
+    res["guard_success_probability"] = float(sim._success_probability(guarded[0])) if rank == 0 else None
+    sim.use_search_seeds()
+    sim.shard_min_paths = 1_000_000
     rep = sim.run_monte_carlo_simulations(wm, 700)
     sim2 = RetirementMonteCarloSimulator(cfg, main_seed_override=2024)
     sim2.shard_min_paths = 0

@@ -51,6 +51,9 @@ def test_sharded_quantiles_and_bands_equal_unsharded(tmp_path, world):
         assert r["class_probe_many_by_candidate"] and r["class_probe_many_by_range"] and r["class_speculation_slots"], r
         assert r["class_search_replays_reference"] and r["class_search_batched"], r
         assert r["class_replicated_equals_sharded"], r
+        # large-n guard of the sharded class API: no n-sized host frame on the ranks other than 0
+        assert r["guard_frame_rows"] == (5003 if r["rank"] == 0 else 0) and r["guard_frame_columns_ok"], r
+        assert r["guard_rank0_frame_equal"] and r["guard_rest_equal"], r
         assert r["unseeded_samples_equal"] and r["unseeded_seed"] == res[0]["unseeded_seed"], (r["unseeded_seed"], res[0]["unseeded_seed"])
     # the compact document built from sharded batches equals the single-process one (built here, same scenario)
     from monte_carlo_retirement_amd import Config
