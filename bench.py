@@ -146,15 +146,18 @@ def aux_hbm_kernels(torch, n):
     ms_k2 = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 100))
     bytes_k2 = 2 * 9 * n                 # min/max pass + bin pass, 8 B value + 1 B flag each
     profiled = None   # the slab pass alone, from the committed rocprofv3 summary of this same command (latest round)
-    for rnd in ("r02", "r01_final"):
+    for rnd, kernel in (("r03", "mcr::rq_slab_kernel<16>"), ("r02", "mcr::rq_count_kernel<16, true>"), ("r01_final", "mcr::rq_bracket_kernel")):
         try:
             with open(os.path.join(REPO, "profiles", rnd, "pmc_summary.json")) as fh:
                 dv = json.load(fh)["derived"]
-            profiled = {"kernel": "mcr::rq_count_kernel<16, true>" if rnd != "r01_final" else "mcr::rq_bracket_kernel",
+            profiled = {"kernel": kernel,
                         "ms": dv["K3_bracket_avg_ms_from_kernel_stats"], "achieved_TBps": dv["K3_bracket_achieved_TBps"],
                         "frac_of_hbm_peak": dv["K3_bracket_achieved_TBps"] * 1e3 / HBM_PEAK_GBS,
                         "traffic_over_algorithmic": dv["K3_bracket_traffic_over_algorithmic"],
+                        "valu_busy": dv.get("K3_valu_busy_slab_pass"),
                         "paths": 10_000_000 if rnd != "r01_final" else 4_000_000,
+                        # a STATIC figure read from a committed file, not measured in this run: this says which build it belongs to
+                        "provenance": dv.get("provenance", {"round": rnd, "commit": None}),
                         "source": f"profiles/{rnd}/pmc_summary.json (rocprofv3 --kernel-trace --stats + FETCH_SIZE/WRITE_SIZE passes)"}
             break
         except (OSError, KeyError, ValueError):
@@ -564,11 +567,13 @@ def main():
         total_paths = n * world * args.steps
         value = total_paths / dt
         achieved_t = ALGO_OPS_PER_PATH * n / (kern_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_prov = None, None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as fh:
-                traffic = json.load(fh).get("path_kernel_count_only_bytes_per_launch")
+                tj = json.load(fh)
+            traffic = tj.get("path_kernel_count_only_bytes_per_launch")
+            traffic_prov = tj.get("provenance", {"round": tj.get("round"), "commit": None})
         out = {
             "metric": "paths/sec (whole node), config.json scenario, 833-month paths, success-count only",
             "value": value,
@@ -594,7 +599,7 @@ def main():
                 "devices": devices_seen,           # every rank's own report (all_gather_object)
             },
             "roofline": {
-                "kernel": "mcr::path_kernel<0, 0, true, false>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
+                "kernel": "mcr::path_kernel<0, 0, true, false, false, 0>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
                 "bound": "valu_fp64",
                 "achieved": achieved_t,
                 "peak": FP64_LANE_OPS_PEAK_T,
@@ -603,6 +608,9 @@ def main():
                 "measured_issue_ceiling": FP64_MEASURED_ISSUE_CEILING_T,
                 "frac_of_measured_issue_ceiling": achieved_t / FP64_MEASURED_ISSUE_CEILING_T,
                 "traffic": traffic,
+                # (`traffic` is a STATIC figure from profiles/pmc_traffic.json — PMC passes cannot run inside this process; the
+                #  provenance says which build and which profiled kernel time it belongs to; `kernel_ms` below is measured live)
+                "traffic_provenance": traffic_prov,
                 "kernel_ms": kern_ms,
                 "algorithmic_ops_per_path": ALGO_OPS_PER_PATH,
                 "note": "no dense contraction and ~0 HBM bytes/path in this variant: the bound is fp64 VALU issue (SURVEY 8d). "

@@ -8,7 +8,7 @@ set -o pipefail
 OUT=${1:?output directory}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-s60"
+B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-s60 --no-search"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $B > "$OUT/kt.log" 2>&1 &&
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/pmc_sq" -- $B > "$OUT/pmc_sq.log" 2>&1 &&

@@ -14,6 +14,7 @@ import os
 import shutil
 import sys
 
+ROUND = 3
 PATHS_COUNT, MONTHS_COUNT = 1_000_000, 833            # bench.py workload (configs[1])
 PATHS_FULL, T_FULL, RY_FULL = 10_000_000, 48, 40       # bench.py hbm_kernels block (configs[2] shape)
 
@@ -24,7 +25,8 @@ def label(kernel_name: str):
         return "K1 path_kernel<0,...> (count-only, 1e6 paths x 833 months)"
     if "path_kernel<2" in k:
         return "K1 path_kernel<2,...> (full output, 1e7 paths x 555 months)"
-    for tag, name in (("rq_count_kernel<16, true>", "K3 rq_count_kernel<16,true> (the one pass over the slab)"),
+    for tag, name in (("rq_slab_kernel<16>", "K3 rq_slab_kernel<16> (the one pass over the slab)"),
+                      ("rq_count_kernel<16, true>", "K3 rq_count_kernel<16,true> (slab pass of rows whose bounds do not fit the bucket table)"),
                       ("rq_count_kernel<16, false>", "K3 rq_count_kernel<16,false> (sample pass)"),
                       ("rq_tiny", "K3 rq_tiny_kernel"), ("rq_refine", "K3 rq_refine_kernel"), ("rq_collect", "K3 rq_collect_kernel"),
                       ("rq_select", "K3 rq_select_kernel"), ("rq_hist", "K3 rq_hist_kernel"),
@@ -53,7 +55,7 @@ def main(src: str, dst: str) -> None:
             for k, cs in per_kernel.items()}
     k0 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<0"))
     k2 = next(v for k, v in summ.items() if k.startswith("K1 path_kernel<2"))
-    kb = summ["K3 rq_count_kernel<16,true> (the one pass over the slab)"]
+    kb = summ["K3 rq_slab_kernel<16> (the one pass over the slab)"]
     m = lambda k, c: k[c]["mean_per_launch"]
     wave_months = (PATHS_COUNT / 64) * MONTHS_COUNT
     stat_rows = list(csv.DictReader(open(stats)))
@@ -78,10 +80,10 @@ def main(src: str, dst: str) -> None:
         "K3_bracket_FETCH_SIZE_x2_bytes_per_launch": 2 * m(kb, "FETCH_SIZE") * 1024,
         "K3_bracket_WRITE_SIZE_bytes_per_launch": m(kb, "WRITE_SIZE") * 1024,
     }
-    kb_ms = next(float(r["AverageNs"]) for r in stat_rows if "rq_count_kernel<16, true>" in r["Name"]) / 1e6
-    k3_names = ("rq_tiny", "rq_count_kernel", "rq_refine", "rq_collect", "rq_select", "rq_hist", "rq_cand", "rq_scan", "rq_init", "rq_flag")
+    kb_ms = next(float(r["AverageNs"]) for r in stat_rows if "rq_slab_kernel<16>" in r["Name"]) / 1e6
+    k3_names = ("rq_tiny", "rq_count_kernel", "rq_slab_kernel", "rq_refine", "rq_collect", "rq_select", "rq_hist", "rq_cand", "rq_scan", "rq_init", "rq_flag")
     k3_rows = [r for r in stat_rows if any(t in r["Name"] for t in k3_names)]
-    calls = max(1, min(int(r["Calls"]) for r in stat_rows if "rq_count_kernel<16, true>" in r["Name"]))
+    calls = max(1, min(int(r["Calls"]) for r in stat_rows if "rq_slab_kernel<16>" in r["Name"]))
     derived["K3_launches_per_call"] = sum(int(r["Calls"]) for r in k3_rows) / calls
     derived["K3_kernel_ms_per_call_sum"] = sum(float(r["TotalDurationNs"]) for r in k3_rows) / calls / 1e6
     derived["K3_valu_busy_slab_pass"] = (m(kb, "SQ_ACTIVE_INST_VALU") * 4 / (1024 * m(kb, "GRBM_GUI_ACTIVE") / 8)) if "SQ_ACTIVE_INST_VALU" in kb else None
@@ -89,14 +91,26 @@ def main(src: str, dst: str) -> None:
     derived["K3_bracket_achieved_TBps"] = derived["K3_bracket_slab_bytes_algorithmic"] / (kb_ms * 1e-3) / 1e12
     derived["K3_bracket_traffic_over_algorithmic"] = (derived["K3_bracket_FETCH_SIZE_x2_bytes_per_launch"] +
                                                         derived["K3_bracket_WRITE_SIZE_bytes_per_launch"]) / derived["K3_bracket_slab_bytes_algorithmic"]
+    # what the figures belong to: the commit the collection ran on (the working tree must be clean when it is sent to the box)
+    import subprocess
+    import datetime
+    try:
+        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, cwd=os.path.dirname(os.path.abspath(__file__))).strip()
+        dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "monte_carlo_retirement_amd", "bench.py"], text=True,
+                                             cwd=os.path.dirname(os.path.abspath(__file__))).strip())
+    except Exception:  # noqa: BLE001
+        commit, dirty = None, None
+    provenance = {"round": ROUND, "commit": commit, "tree_dirty_when_summarised": dirty, "collected_utc": datetime.datetime.utcfromtimestamp(os.path.getmtime(stats)).isoformat() + "Z",
+                  "K1_count_kernel_ms": k1_ms, "K3_slab_kernel_ms": kb_ms}
+    derived["provenance"] = provenance
     json.dump({
-        "command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-s60 "
+        "command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-s60 --no-search "
                    "(separate passes: SQ, SQ instruction mix, FETCH_SIZE, WRITE_SIZE; tools/collect_profiles.sh)",
         "note": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM)",
         "kernels": summ, "derived": derived,
     }, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     json.dump({
-        "round": 2, "source": os.path.join(dst, "pmc_summary.json"),
+        "round": ROUND, "source": os.path.join(dst, "pmc_summary.json"), "provenance": provenance,
         "path_kernel_count_only_bytes_per_launch": derived["K1_count_hbm_bytes_per_launch"],
         "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of 1e6 paths; the algorithmic traffic of the count-only kernel "
                 "is ~3907 workgroups x (2 + <=102) 8-byte atomics",
