@@ -17,6 +17,14 @@ for cycle in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record(); A.band_quantiles(b, n); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    print(f"cycle {cycle}: slab at {b.slab.data_ptr():#x} scratch at {b._rq_scratch.data_ptr():#x}  steady median {statistics.median(ts[8:]):.3f} ms  min {min(ts):.3f}", flush=True)
+    # a plain streaming read of the same slab on the same allocation (no scratch, no candidates, torch's own reduction kernel)
+    ss = []
+    for _ in range(12):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record(); b.slab[:, :n].sum(); e1.record(); torch.cuda.synchronize()
+        ss.append(e0.elapsed_time(e1))
+    gb = 8 * n * b.slab.shape[0] / 1e9
+    print(f"cycle {cycle}: slab at {b.slab.data_ptr():#x} scratch at {b._rq_scratch.data_ptr():#x}  steady median {statistics.median(ts[8:]):.3f} ms  min {min(ts):.3f}"
+          f"  | torch.sum of the slab {statistics.median(ss[4:]):.3f} ms = {gb / statistics.median(ss[4:]):.2f} TB/s", flush=True)
     del b
     torch.cuda.empty_cache()

@@ -4,7 +4,7 @@ set -o pipefail
 OUT=${1:?output directory}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt" -- python3 tools/k3_alloc_modes.py 10000000 6 > "$OUT/kt.log" 2>&1 || { tail -5 "$OUT/kt.log"; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt" -- python3 tools/k3_alloc_modes.py 10000000 ${CYCLES:-6} > "$OUT/kt.log" 2>&1 || { tail -5 "$OUT/kt.log"; exit 1; }
 grep cycle "$OUT/kt.log" | cut -c60-
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys, statistics, collections
