@@ -548,16 +548,19 @@ class RetirementMonteCarloSimulator:
         return self._probe_many([working_months], num_simulations)[int(working_months)]
 
     def _speculation_slots(self, num_simulations: int) -> int:
-        """How many candidate months one round of the search may evaluate together at the cost of one.
-        On one GPU concurrency between candidates only buys ~25 % (measured, 50 000-path probes), less
-        than a wrong guess costs, so nothing is evaluated on speculation there (the verification window,
-        whose months are all needed, is still one batch).  When small batches are split by candidate
-        across the ranks of a process group, every rank can take one candidate for free."""
+        """How many candidate months one round of the search may evaluate together at the cost of (about) one.
+        Under a process group small batches are split by candidate across the ranks: every rank takes one candidate for
+        free.  On ONE GPU a small probe is latency-bound — 50 000 paths are 782 wavefronts on 1 024 SIMDs — and candidates of
+        one call share their accumulation sweep (`mcr_probe_months_rng`): measured at 50 000 paths, months 217+, one candidate
+        1.19 ms, two 1.40, four 1.82 (tools/probe_latency.py).  Three candidates a round = the bisection's midpoint and both
+        midpoints of the next level (two levels per round), or three bracket points: 1.6 ms instead of 2 x 1.19.  A month the
+        reference would not have probed never reaches the curve or the callback (`ahead` in find_minimum_working_months).
+        Large probes (>= 200 000 paths) fill the chip on their own: nothing is evaluated on speculation there."""
         if D.is_active() and int(num_simulations) < self.shard_min_paths:
             import torch.distributed as dist
 
             return dist.get_world_size()
-        return 1
+        return 3 if int(num_simulations) < 200_000 else 1
 
     # ---- search driver (:1138-1342) ------------------------------------------------------------
     def find_minimum_working_months(

@@ -364,11 +364,12 @@ def test_batched_search_equals_one_probe_at_a_time():
     a._probe_many = lambda months, n: (calls_a.append(len(months)), many_a(months, n))[1]
     ra = a.find_minimum_working_months(verbose=False, progress_callback=ea.append)
     b = RetirementMonteCarloSimulator(cfg)
+    assert b._speculation_slots(20_000) == 3 and b._speculation_slots(1_000_000) == 1   # one GPU: small probes only
+    b._speculation_slots = lambda n: 1          # strictly the reference's sequence: one month per round, one launch per month
     many_b = b._probe_many
     b._probe_many = lambda months, n: {m: (calls_b.append(1), many_b([m], n))[1][m] for m in months}
     rb = b.find_minimum_working_months(verbose=False, progress_callback=eb.append)
     assert ra == rb and ea == eb
-    assert b._speculation_slots(20_000) == 1
     assert max(calls_a) > 1 and len(calls_a) < len(calls_b) <= len(rb[2])   # fewer, wider calls
 
 
