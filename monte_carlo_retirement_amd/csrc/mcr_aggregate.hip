@@ -968,7 +968,7 @@ __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))
                 // a batch = ONE contiguous 16 KB tile of the row per workgroup (kUnroll chunks a grid stride apart measured 1 % slower)
                 const int64_t i = t * step + ((int64_t)blockIdx.x * kUnroll + u) * kRqBlock + threadIdx.x;
                 okv[u] = i < n_pairs;
-                v[u] = okv[u] ? __builtin_nontemporal_load(&r2[i]) : d2_t{0.0, 0.0};
+                v[u] = okv[u] ? __builtin_nontemporal_load(&r2[i]) : d2_t{0.0, 0.0};   // (plain loads: 2.21 -> 2.37 ms)
             }
         };
         if (trips > 0) fetch(0);
