@@ -55,6 +55,7 @@ struct KernelIO {
     int32_t snap_months[MCR_MAX_PROBE_CANDIDATES];   // ascending
     int32_t cand_out[MCR_MAX_PROBE_CANDIDATES];      // PHASE 2: counter block of candidate c = counters + cand_out[c] * MCR_N_COUNTERS
 };
+constexpr int kSplitVotePairs = 16;   // SPLIT: pairs of months between two stop votes of a workgroup (a power of two)
 constexpr int kSnapFields = 10;   // b1 b2 c1 c2 gacc1 gacc2 infl contrib | pre_fail | Philox carry words
 
 // NaN OUTPUT values travel as integer bit patterns (robust against any no-NaN math assumption: the
@@ -80,9 +81,20 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 #ifndef MCR_K1_WAVES_ATTR
 #define MCR_K1_WAVES_ATTR
 #endif
-template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0>
-__global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
+// SPLIT = true (count-only Philox variants; launches that leave SIMDs idle — a lone 50 000-path search probe is 782
+// wavefronts on 1 024 SIMDs and runs at ~12 cycles per instruction, latency-bound): the workgroup has 2 x kBlock threads
+// for its kBlock paths.  Threads kBlock .. 2 kBlock - 1 are PRODUCERS: they run growth_rows2 (Philox, Box-Muller, exp) one
+// pair of months ahead into a double-buffered stage; threads 0 .. kBlock - 1 are CONSUMERS: the state machine.  The two
+// halves of a month's dependency chain then run on different SIMDs of the CU.  One workgroup barrier per pair of months
+// hands a buffer over; every wave executes the same number of them (no early exit when all lanes have failed) or has
+// terminated.  The arithmetic of every path is unchanged: counts are bit-identical to SPLIT = false.
+template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
+    static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
+    constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
+    const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
+    const bool producer = SPLIT && threadIdx.x >= (unsigned)kBlock;                  // wave-uniform (kBlock = 4 wavefronts)
     // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
     // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
     const DevParams& P = PHASE == 2 ? cand_params[blockIdx.y] : P_arg;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     // the block counters.
     constexpr bool kStaged = RNG == (int)MCR_RNG_PHILOX && !INJ;
     __shared__ __align__(16) double tab_s[kTabDoubles];
-    __shared__ __align__(16) double stage_s[kStaged ? kStageDoubles : 1];
+    __shared__ __align__(16) double stage_s[kStaged ? (SPLIT ? 2 : 1) * kStageDoubles : 1];
     // Per-path values that are written once or twice in a lifetime and read at the very end (first-year withdrawals,
     // YearsToRuin) live in the lane's own LDS column in the variants with per-path outputs: held to 5 waves per SIMD those
     // variants had no registers for them (round 2: 12 / 36 bytes of scratch per lane, 4-12 VGPRs spilled).
@@ -109,12 +121,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     const unsigned long long tl_t0 = wall_clock64();
 #endif
     double* tab = tab_s;
-    load_math_tables(tab, threadIdx.x, kBlock);
+    load_math_tables(tab, threadIdx.x, kThreads);
     ZigTables zig{nullptr, nullptr, nullptr};
-    if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw, threadIdx.x, kBlock);
+    if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw, threadIdx.x, kThreads);
     // Philox stream: the gross factors of two months at a time, staged per lane (growth_rows2)
-    double* stage = stage_s + (kStaged ? threadIdx.x : 0);
-    double* sum_col = sum_s + (kSumLds ? threadIdx.x : 0);     // [0] first-year gross, [kBlock] first-year real gross, [2 kBlock] YearsToRuin bits
+    double* stage = stage_s + (kStaged ? tid : 0);
+    double* sum_col = sum_s + (kSumLds ? tid : 0);     // [0] first-year gross, [kBlock] first-year real gross, [2 kBlock] YearsToRuin bits
     double* lock_lds = reinterpret_cast<double*>(smem_raw + (RNG == (int)MCR_RNG_NUMPY ? kZigLdsBytes : 0));
     unsigned int* blk = reinterpret_cast<unsigned int*>(lock_lds + (size_t)P.n_lock_slots * kBlock);
     // blk[0] = success count; blk[1 .. 1+ry+2) = ruin bins; then [ry+1] done-years histogram; then the
@@ -122,10 +134,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     const int ry = P.retirement_years;
     const int n_blk = 1 + (ry + 2) + (ry + 1);
     const int n_hist = (PHASE == 0 && io.out.hist_bins != nullptr) ? io.out.hist_n_bins : 0;
-    for (int k = threadIdx.x; k < n_blk + n_hist; k += kBlock) blk[k] = 0u;
+    for (int k = threadIdx.x; k < n_blk + n_hist; k += kThreads) blk[k] = 0u;
     __syncthreads();
 
-    const uint64_t local = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t local = (uint64_t)blockIdx.x * kBlock + (unsigned)tid;
     const bool valid = local < io.n_paths;
     const uint64_t li = valid ? local : (io.n_paths - 1);  // tail lanes shadow the last path, write nothing
     const uint64_t path = io.path_begin + li;
@@ -162,19 +174,30 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     // path: 8.40 -> 7.98 ms at exactly 10^6 paths (profiles/r02/k1_timeline_*.txt).
     const int prio_t1 = P.total_months / 2, prio_t2 = (P.total_months * 3) / 4, prio_t3 = (P.total_months * 9) / 10;
     __builtin_amdgcn_s_setprio(3);
+    bool wg_dead = false;      // SPLIT: no consumer lane of the workgroup is alive any more (wave-uniform, agreed at a barrier)
+    bool lane_alive = true;    // SPLIT: this consumer lane still has months to simulate
     auto begin_month = [&](int row) {
         if (row == prio_t1) __builtin_amdgcn_s_setprio(2);
         else if (row == prio_t2) __builtin_amdgcn_s_setprio(1);
         else if (row == prio_t3) __builtin_amdgcn_s_setprio(0);
         if (kStaged && (row & 1) == 0) {
-            if ((row & 2) == 0) growth_rows2<0>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
-            else growth_rows2<1>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+            if (SPLIT) {
+                // the producers have staged the pair (row, row + 1) in buffer (row >> 1) & 1.  Every kSplitVotePairs-th pair the barrier
+                // also votes (a voting barrier costs about two plain ones: every 6th pair 0.93 ms per lone probe, every 16th 0.88): once no consumer lane of the workgroup is alive, producers and consumers stop together (the unsplit
+                // kernel lets a wave leave as soon as all of ITS lanes have failed)
+                if (wg_dead) return;
+                if (((row >> 1) & (kSplitVotePairs - 1)) == 0) { if (__syncthreads_or(__builtin_amdgcn_ballot_w64(lane_alive) != 0ull ? 1 : 0) == 0) wg_dead = true; }
+                else __syncthreads();
+            } else {
+                if ((row & 2) == 0) growth_rows2<0>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+                else growth_rows2<1>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, stage, carry);
+            }
         }
     };
     // gross factors of month `row` (:522-532)
     auto growth = [&](int row, double& g1, double& ginf, double& g2) {
         if (kStaged) {
-            const double* c = stage + (size_t)(3 * (row & 1)) * kBlock;
+            const double* c = stage + (size_t)(3 * (row & 1)) * kBlock + (SPLIT ? (size_t)((row >> 1) & 1) * kStageDoubles : 0);
             g1 = c[0]; ginf = c[kBlock]; g2 = c[2 * kBlock];
             return;
         }
@@ -216,10 +239,36 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
             *snap_at(snap_i, 0) = b1; *snap_at(snap_i, 1) = b2; *snap_at(snap_i, 2) = c1; *snap_at(snap_i, 3) = c2;
             *snap_at(snap_i, 4) = gacc1; *snap_at(snap_i, 5) = gacc2; *snap_at(snap_i, 6) = infl; *snap_at(snap_i, 7) = contrib;
             *snap_at(snap_i, 8) = pre_fail ? 1.0 : 0.0;
-            store_bits(snap_at(snap_i, 9), ((unsigned long long)carry.w3 << 32) | (unsigned long long)carry.w2);
+            if (!SPLIT) store_bits(snap_at(snap_i, 9), ((unsigned long long)carry.w3 << 32) | (unsigned long long)carry.w2);   // (SPLIT: the producer's)
         }
         ++snap_i;
     };
+    if (SPLIT && producer) {
+        // Rows [first_row, last_row), a pair per iteration, one barrier per pair: exactly the barriers the consumers execute
+        // in begin_month at every even row they visit (they visit every row of this range, in order, and never leave early).
+        const int first_row = PHASE == 2 ? (wm & ~1) : 0;                 // PHASE 2 resumes with the pair that holds row wm
+        const int last_row = PHASE == 1 ? wm : P.total_months;
+        if (PHASE == 2) {
+            const unsigned long long cw = f64_bits(*snap_at((int)blockIdx.y, 9));
+            carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
+        }
+        // PHASE 1: the Philox words carried past the end of candidate month m are those in hand once the pair that holds row
+        // m - 1 has been generated (m = 0: none yet) — what the unsplit kernel stores from its single `carry`
+        auto put_carry = [&]() {
+            if (valid) store_bits(snap_at(snap_i, 9), ((unsigned long long)carry.w3 << 32) | (unsigned long long)carry.w2);
+            ++snap_i;
+        };
+        if (PHASE == 1) while (snap_i < io.n_snap && io.snap_months[snap_i] == 0) put_carry();
+        for (int row = first_row; row < last_row; row += 2) {
+            double* st = stage + (size_t)((row >> 1) & 1) * kStageDoubles;
+            if ((row & 2) == 0) growth_rows2<0>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, st, carry);
+            else growth_rows2<1>(P, GR, io.seed, io.stream_id, path, (uint32_t)row >> 2, tab, st, carry);
+            if (PHASE == 1) while (snap_i < io.n_snap && ((io.snap_months[snap_i] - 1) >> 1) == (row >> 1)) put_carry();
+            if (((row >> 1) & (kSplitVotePairs - 1)) == 0) { if (__syncthreads_or(0) == 0) return; }   // (the consumers' vote, begin_month)
+            else __syncthreads();
+        }
+        return;
+    }
     if (PHASE == 1) while (snap_i < io.n_snap && io.snap_months[snap_i] == 0) save_snapshot();
     if (PHASE == 2) {
         const int c = blockIdx.y;
@@ -267,7 +316,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
     for (; year < ry; ++year) {
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
+        if (!SPLIT && __builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
+        if (SPLIT) { lane_alive = alive; if (wg_dead) break; }           // (SPLIT: the wave keeps pace with its producers' barriers until the workgroup votes to stop)
         double tg1 = 0.0, tg2 = 0.0, treal = 0.0;  // :635-637
         bool yfail = false;                        // :638
         int fail_rmi = 0;
@@ -287,7 +337,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 :
                     if (S.indexed) {
                         nominal = S.amount * price;                    // :661-665
                     } else {
-                        double* slot = lock_lds + (size_t)S.lock_slot * kBlock + threadIdx.x;
+                        double* slot = lock_lds + (size_t)S.lock_slot * kBlock + tid;
                         if (rmi == S.start_month) *slot = S.amount * price;  // :667-671 (first active month)
                         nominal = *slot;                               // :672-674
                     }
@@ -852,7 +902,15 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     return MCR_OK;
 }
 
-constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)(kStageDoubles + 3 * kBlock) * sizeof(double);   // (upper bound over the variants)
+constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)(2 * kStageDoubles + 3 * kBlock) * sizeof(double);   // (upper bound over the variants)
+
+// Launches of at most this many path-wavefronts take the producer / consumer split (SPLIT = true): up to 3 per SIMD a
+// wavefront is latency-bound and the second wave per path hides half of its chain; above it the chip is busy either way
+// and the split only adds barriers.  MCR_K1_SPLIT_MAX_WAVES overrides it (0 = never).
+static unsigned split_max_waves() {   // (read at every launch: tests compare both forms in one process)
+    const char* e = std::getenv("MCR_K1_SPLIT_MAX_WAVES");
+    return (e && *e) ? (unsigned)std::strtoul(e, nullptr, 10) : 3072u;
+}
 static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng, int n_hist_bins = 0) {
     // the dynamic part only: the math tables and the stage of growth factors are static LDS of the kernel
     return (numpy_rng ? (size_t)kZigLdsBytes : (size_t)0) +
@@ -917,6 +975,17 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
     // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
     // shocks (parity hook) always take the full-output variant, whose every store is null-checked
+    const bool split = !injected && !np_rng && mode == 0 && (uint64_t)grid.x * (kBlock / 64) <= split_max_waves();
+    if (split) {
+        const dim3 block2(2 * kBlock);
+#define MCR_LAUNCH_S(T, A) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 0, true>), grid, block2, lds, stream, d, io, (const DevParams*)nullptr)
+        if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH_S(true, true); else MCR_LAUNCH_S(true, false); }
+        else { if (d.any_annual_tax) MCR_LAUNCH_S(false, true); else MCR_LAUNCH_S(false, false); }
+#undef MCR_LAUNCH_S
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return hip_fail(es, "path_kernel launch (split)");
+        return MCR_OK;
+    }
 #define MCR_LAUNCH(M, R, T, A, I) hipLaunchKernelGGL((path_kernel<M, R, T, A, I>), grid, block, lds, stream, d, io, (const DevParams*)nullptr)
 #define MCR_LAUNCH_T(M, R, I)                                                                      \
     do {                                                                                           \
@@ -1025,10 +1094,16 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
     hipError_t e = hipMemcpyAsync((char*)mem + snap_bytes, blocks.data(), blocks_bytes, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
         const dim3 block(kBlock), g1((unsigned)((n_paths + kBlock - 1) / kBlock)), g2(g1.x, (unsigned)n_cand);
+        // (either phase takes the producer / consumer split on its own while its launch leaves SIMDs idle)
+        const bool split1 = (uint64_t)g1.x * (kBlock / 64) <= split_max_waves();
+        const bool split2 = (uint64_t)g2.x * g2.y * (kBlock / 64) <= split_max_waves();
+        const dim3 block2(2 * kBlock);
 #define MCR_PHASES(T, A)                                                                                          \
         do {                                                                                                       \
-            hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 1>), g1, block, lds, stream, top, io, d_blocks);    \
-            hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2>), g2, block, lds, stream, top, io, d_blocks);    \
+            if (split1) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 1, true>), g1, block2, lds, stream, top, io, d_blocks); \
+            else hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 1>), g1, block, lds, stream, top, io, d_blocks);    \
+            if (split2) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2, true>), g2, block2, lds, stream, top, io, d_blocks); \
+            else hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2>), g2, block, lds, stream, top, io, d_blocks);    \
         } while (0)
         if (top.any_real_rate) { if (top.any_annual_tax) MCR_PHASES(true, true); else MCR_PHASES(true, false); }
         else { if (top.any_annual_tax) MCR_PHASES(false, true); else MCR_PHASES(false, false); }

@@ -375,3 +375,33 @@ def test_any_subset_of_output_pointers():
                 assert np.all(bufs[k] == SENT), (k, ctx)
         for k in vecs:
             assert bufs[k].tolist() == (full[k].tolist() if want[k] else [0] * bufs[k].size), (k, ctx)
+
+
+def test_producer_consumer_split_counts_are_bit_identical(monkeypatch):
+    """Small count-only launches (<= 3 072 path-wavefronts: search probes) run the SPLIT form of the path kernel — producer
+    waves stage the growth factors a pair of months ahead, consumer waves run the state machine, one barrier per pair, a
+    stop vote every 16th.  The arithmetic of a path is the same instructions in the same order: every counter, ruin-year
+    bin, observation count and histogram bin must equal the unsplit launch — also when whole workgroups fail early, for
+    odd / even / zero working months, ragged sizes, and through the shared-accumulation probes of the search."""
+    rng = np.random.default_rng(int(os.environ.get("MCR_SPLIT_FUZZ_SEED", "20261004")))
+    cfgs = load_golden("paths_injected.json")
+    edges = np.geomspace(1.0, 1e12, 41)
+    for it in range(int(os.environ.get("MCR_SPLIT_FUZZ_ROUNDS", "24"))):
+        g = cfgs[int(rng.integers(len(cfgs)))]
+        p = params_from_config(Config(**g["cfg"]))
+        wm = int(rng.choice([0, 1, 2, 11, 12, 13, g["working_months"], g["working_months"] + 1, int(rng.integers(0, 400))]))
+        n = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 50_000, int(rng.integers(1, 150_000))]))
+        seed, stream, begin = int(rng.integers(0, 2**63)), int(rng.integers(2)), int(rng.choice([0, 7, 2**40 + 3]))
+        out = {}
+        for mode, waves in (("split", "3072"), ("plain", "0")):
+            monkeypatch.setenv("MCR_K1_SPLIT_MAX_WAVES", waves)
+            out[mode] = E.run_batch_host(p, seed, stream, begin, n, wm, want_summary=False, want_trajectories=False, hist_edges=edges)
+        for k in ("counters", "wr_obs_counts", "ruin_year_bins", "hist_bins"):
+            assert out["split"][k].tolist() == out["plain"][k].tolist(), (it, g["name"], wm, n, k)
+        months = sorted({int(m) for m in rng.integers(0, 300, int(rng.integers(2, 7)))})
+        if len(months) >= 2:
+            probes = {}
+            for mode, waves in (("split", "3072"), ("plain", "0")):
+                monkeypatch.setenv("MCR_K1_SPLIT_MAX_WAVES", waves)
+                probes[mode] = E.probe_months(p, seed, stream, begin, min(n, 60_000), months).cpu().tolist()
+            assert probes["split"] == probes["plain"], (it, g["name"], months, n)
