@@ -47,10 +47,24 @@ def main():
     time.sleep(0.01 * rank)   # different timestamps per rank
     unseeded = RetirementMonteCarloSimulator(Config(**dict(cfg.model_dump(by_alias=True), seed=None)))
     own = RetirementMonteCarloSimulator(Config(**dict(cfg.model_dump(by_alias=True), seed=99 + rank)))
+    # distributed.local_only(): inside it this thread computes as if no group existed (bench.py's cross-check of the
+    # candidate-split search); the state nests and is restored, other threads are unaffected
+    import threading
+    seen = {}
+    with D.local_only():
+        seen["inside"] = D.is_active()
+        seen["broadcast_inside"] = D.broadcast_int(1000 + rank)          # no collective: every rank keeps its own value
+        with D.local_only():
+            seen["nested"] = D.is_active()
+        seen["after_nested"] = D.is_active()
+        t = threading.Thread(target=lambda: seen.__setitem__("other_thread", D.is_active()))
+        t.start(); t.join()
+    seen["after"] = D.is_active()
+    seen["broadcast_after"] = D.broadcast_int(1000 + rank)               # rank 0's value everywhere again
     with open(f"{out_path}.{rank}", "w") as fh:
         json.dump({"main_seed": unseeded.main_seed, "own_seed": own.main_seed, "rank": rank, "world": world, "shards": shards, "success": red.success, "paths": red.paths,
                    "wr": red.wr_obs_counts.tolist(), "ruin": red.ruin_year_bins.tolist(),
-                   "prob": red.success_probability_pct, "minmax": mm.tolist(), "active": D.is_active()}, fh)
+                   "prob": red.success_probability_pct, "minmax": mm.tolist(), "active": D.is_active(), "local_only": seen}, fh)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -72,3 +72,6 @@ def test_sharded_counts_equal_single_process(tmp_path, oracle, world, n_total):
         assert r["prob"] == res[0]["prob"]
         assert r["minmax"] == [10.0, 100.0 * world]
         assert r["main_seed"] == res[0]["main_seed"] and r["own_seed"] == 99 + r["rank"]   # seed=None: rank 0's seed everywhere
+        lo = r["local_only"]
+        assert (lo["inside"], lo["nested"], lo["after_nested"], lo["other_thread"], lo["after"]) == (False, False, False, True, True), lo
+        assert lo["broadcast_inside"] == 1000 + r["rank"] and lo["broadcast_after"] == 1000
