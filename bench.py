@@ -170,10 +170,12 @@ def aux_hbm_kernels(torch, n):
         "K3_row_quantiles": {"ms": ms_k3, "rows": 2 * T + ry, "algorithmic_read_bytes": bytes_k3,
                              "GBps": bytes_k3 / ms_k3 / 1e6, "frac_of_hbm_peak": bytes_k3 / ms_k3 / 1e6 / HBM_PEAK_GBS,
                              "fallback_rows": fallback_rows, "slab_pass_profiled": profiled,
-                             "note": "one call over the [2T+ry] slab (bands of all rows): six launches + one word read back, incl. the result "
-                                     "download. Algorithmic bytes = ONE read of the slab; the counting pass that does it runs at ~5 TB/s, the "
-                                     "rest is the two sampling steps before it and the per-row cell selection after it (profiles/). "
-                                     "fallback_rows = rows that needed the 4-pass radix select (-1: rows too short for the bracketed route)"},
+                             "note": "one call over the [2T+ry] slab (bands of all rows), steady state (3 warm-up calls, median of 15): seven "
+                                     "launches + one word read back, results written straight into pinned host memory. Algorithmic bytes = ONE read "
+                                     "of the slab; the pass that does it (rq_slab_kernel) runs at 5.3-6.0 TB/s depending on where the driver placed "
+                                     "this process's slab (DESIGN.md 5), the rest is the two sampling steps before it and the per-row cell selection "
+                                     "after it (profiles/). fallback_rows = rows that needed the 4-pass radix select (-1: rows too short for the "
+                                     "bracketed route)"},
         "K2_histogram": {"ms": ms_k2, "algorithmic_bytes": bytes_k2, "GBps": bytes_k2 / ms_k2 / 1e6},
     }
 

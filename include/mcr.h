@@ -309,16 +309,19 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
  * Row-wise quantiles with pandas' semantics (linear interpolation between order statistics,
  * NaNs skipped): for each of n_rows rows of `n` doubles at rows[r*row_stride + i], writes
  * out[r*n_q + j] = quantile(q[j]) (NaN for an all-NaN row) and, if counts != NULL,
- * counts[r] = number of non-NaN entries.  rows/out/counts are DEVICE pointers; q is HOST.
+ * counts[r] = number of non-NaN entries.  rows/out/counts are DEVICE pointers (out / counts may also be pinned,
+ * device-visible host memory — a few KB the kernels write directly: no download after the call); q is HOST.
  * scratch: device buffer of mcr_row_quantiles_scratch_bytes(n_rows, n_q, n) bytes (selection state, digit and
  * sub-bin histograms, per-row candidate buffers of n/64 + 4096 keys and n/8 + 4096 values, cell lists); 0 =
  * unsupported shape.
  *
  * mcr_row_quantiles picks the route by row length.  Short rows: the exact radix select (8 digit passes,
- * 4 of them over the slab), fully asynchronous.  Rows of >= 2^14 entries, SIX launches: the first 4096 entries of
+ * 4 of them over the slab), fully asynchronous.  Rows of >= 2^14 entries, SEVEN launches: the first 4096 entries of
  * every row are sorted in LDS (coarse brackets); a counting pass over a sample (the first n/32 entries) and a small
- * per-row kernel turn them into fine brackets; ONE pass over the slab counts the keys around the brackets (with
- * sub-histograms inside them) and compacts the few % inside; two per-row kernels locate every target in one
+ * per-row kernel turn them into fine brackets; ONE pass over the slab counts the entries around the brackets (with
+ * sub-histograms inside them) and compacts the few % inside — two kernels side by side: rows whose bracket bounds fit a
+ * 2048-bucket value table take the table-driven one (-0.0 is counted and returned as +0.0 there), the others a generic
+ * search; two per-row kernels locate every target in one
  * sub-bin, collect that bin's keys and select among them.  Rows whose counts do not prove their brackets right
  * take the radix passes afterwards.  The result is exact on either route.  The second route reads one word back
  * from the device (how many rows need the radix passes): it synchronises hip_stream ONCE per call.
