@@ -70,6 +70,8 @@ def test_bench_single_gpu_line_has_the_contract_keys():
     assert cb["host_cores"] >= cb["usable_cores"] >= 4 and isinstance(cb["cpu_model"], str) and cb["cpu_model"]
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_of_measured_issue_ceiling"}
     assert out["s60"]["paths_counted"] == 400000 and out["hbm_kernels"]["K3_row_quantiles"]["rows"] == 136
+    k3 = out["hbm_kernels"]["K3_row_quantiles"]
+    assert len(k3["by_allocation_ms"]) == 3 and k3["ms"] == sorted(k3["by_allocation_ms"])[1] and k3["fallback_rows"] == 0
     assert out["s60"]["exchange"] == "none (1 GPU)" and "inside the count-only path kernel" in out["s60"]["workload"]
     assert out["s60"]["success_probability"] == out["s60_data_ranged"]["success_probability"]
     c = out["config"]
