@@ -425,6 +425,9 @@ def launch_ranks(n_ranks: int) -> int:
     sys.stderr.flush()
     for f in logs:
         f.close()
+    import shutil
+
+    shutil.rmtree(logdir, ignore_errors=True)
     return rc
 
 
