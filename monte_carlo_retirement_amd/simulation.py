@@ -391,6 +391,10 @@ class RetirementMonteCarloSimulator:
         logger.debug(f"Running {n} simulations on HIP device {dev} for {wm} working months.")
         batch = E.DeviceBatch(self._current_params(), wm, n, want="full", device=dev)
         batch.launch(self._batch_rng(n), self._stream_id, 0)
+        # The 5 sampled columns are the ones trajectory_df.sample(n=5, axis=1, random_state=main_seed) picks (:1063-1078):
+        # pandas draws them with RandomState(seed).choice(n, 5, replace=False), which permutes all n indices — 7 ms at 1e6
+        # paths, as long as the kernel itself.  It is host-only work: done HERE, while the (asynchronous) launch runs.
+        picked = self._sample_columns(n)
 
         summary_df = _summary_frame(batch, n)
 
@@ -401,18 +405,11 @@ class RetirementMonteCarloSimulator:
         wr_percentiles_df = pd.DataFrame(wr_q, columns=pd.Index(list(A.WR_QUANTILES), dtype="float64"))
         wr_observation_counts = [int(v) for v in wr_counts.tolist()]
 
-        # 5 sample paths: the columns trajectory_df.sample(n=5, axis=1, random_state=main_seed) picks
-        # (:1063-1078).  pandas draws them with RandomState(seed).choice(n, 5, replace=False).
         sample_trajectories_list: Optional[List[List[float]]] = None
         sample_real_trajectories_list: Optional[List[List[float]]] = None
-        k = min(n, 5)
-        if k > 0:
-            try:
-                picked = np.random.RandomState(self.main_seed).choice(n, size=k, replace=False)
-                sample_trajectories_list = _gather_columns(batch.trajectory, picked).tolist()
-                sample_real_trajectories_list = _gather_columns(batch.real_trajectory, picked).tolist()
-            except ValueError as ve:  # e.g. main_seed >= 2**32: the reference logs and returns None (:1079-1083)
-                logger.error(f"Error sampling trajectories: {ve}")
+        if picked is not None:
+            sample_trajectories_list = _gather_columns(batch.trajectory, picked).tolist()
+            sample_real_trajectories_list = _gather_columns(batch.real_trajectory, picked).tolist()
         return (
             summary_df,
             trajectory_percentiles_df,
@@ -422,6 +419,19 @@ class RetirementMonteCarloSimulator:
             sample_real_trajectories_list,
             wr_observation_counts,
         )
+
+    def _sample_columns(self, n: int):
+        """Indices of the sampled paths — ``RandomState(main_seed).choice(n, min(n, 5), replace=False)``, what pandas'
+        ``sample(n=5, axis=1, random_state=main_seed)`` draws (:1063-1078) — or None where the reference logs an error and
+        returns no samples (e.g. main_seed >= 2**32, :1079-1083).  The same on every rank of a process group."""
+        k = min(int(n), 5)
+        if k <= 0:
+            return None
+        try:
+            return np.random.RandomState(self.main_seed).choice(int(n), size=k, replace=False)
+        except ValueError as ve:
+            logger.error(f"Error sampling trajectories: {ve}")
+            return None
 
     def _run_sharded(self, wm: int, n: int):
         """run_monte_carlo_simulations with one process per GPU (torch.distributed initialised): every rank
@@ -440,6 +450,7 @@ class RetirementMonteCarloSimulator:
         batch = E.DeviceBatch(self._current_params(), wm, max(count, 1), want="full", device=dev)
         if count > 0:
             batch.launch(self._batch_rng(n), self._stream_id, begin, count)
+        picked = self._sample_columns(n)          # (host work under the asynchronous launch; identical on every rank)
         comm = D._comm_device()
         # ---- per-path summary: pack [7, per] (six doubles + the flag), all-gather, trim ----
         fields = list(_FIELD_OF.values())
@@ -477,22 +488,17 @@ class RetirementMonteCarloSimulator:
         wr_observation_counts = [int(v) for v in wr_counts.tolist()]
         # ---- the 5 sampled paths: owner ranks fill their columns, the rest stays 0, sum-reduce ----
         samples = real_samples = None
-        k = min(n, 5)
-        if k > 0:
-            try:
-                picked = np.random.RandomState(self.main_seed).choice(n, size=k, replace=False)
-                T = batch.sizes.trajectory_len
-                buf = torch.zeros((2, k, T), dtype=torch.float64, device=batch.trajectory.device)
-                for j, g in enumerate(picked):
-                    if begin <= g < begin + count:
-                        buf[0, j] = batch.trajectory[:, g - begin]
-                        buf[1, j] = batch.real_trajectory[:, g - begin]
-                buf = buf.to(comm)
-                D.all_reduce_sum_(buf)
-                samples = buf[0].cpu().numpy().tolist()
-                real_samples = buf[1].cpu().numpy().tolist()
-            except ValueError as ve:
-                logger.error(f"Error sampling trajectories: {ve}")
+        if picked is not None:    # (None on every rank or on none: same seed, same n — the collective below cannot be skipped by one rank)
+            T = batch.sizes.trajectory_len
+            buf = torch.zeros((2, len(picked), T), dtype=torch.float64, device=batch.trajectory.device)
+            for j, g in enumerate(picked):
+                if begin <= g < begin + count:
+                    buf[0, j] = batch.trajectory[:, g - begin]
+                    buf[1, j] = batch.real_trajectory[:, g - begin]
+            buf = buf.to(comm)
+            D.all_reduce_sum_(buf)
+            samples = buf[0].cpu().numpy().tolist()
+            real_samples = buf[1].cpu().numpy().tolist()
         return (summary_df, trajectory_percentiles_df, samples, wr_percentiles_df,
                 real_trajectory_percentiles_df, real_samples, wr_observation_counts)
 
