@@ -187,6 +187,16 @@ int mcr_query_sizes(const mcr_params* p, int32_t working_months, mcr_sizes* out)
  * MCR_ERR_INVALID_ARG (message via mcr_last_error) instead of computing with out-of-range inputs.  Not
  * checkable up front: balances are assumed to stay within 1e-6 .. 1e15 (unscaled fp64 division). */
 int mcr_validate_params(const mcr_params* p);
+/* The five sampled paths of run_monte_carlo_simulations: trajectory_df.sample(n=5, axis=1, random_state=main_seed)
+ * (simulation.py:1063-1078) = numpy.random.RandomState(seed).choice(n, k, replace=False), i.e. the first k entries of
+ * RandomState(seed).permutation(n): MT19937 seeded with init_genrand(seed), a Fisher-Yates shuffle from the top with
+ * masked-rejection bounded draws.  NumPy shuffles an n-element array to get them (7 ms at n = 1e6, 0.7 s at 1e8 — as
+ * long as the path kernel takes for n paths); this restatement only generates the n - 1 draws and traces the k wanted
+ * positions back through the swaps: the same indices, bit for bit (tests/test_abi_cpu.py), at about half the time, so the
+ * draw hides under the asynchronous kernel launch at every n.  Host-only (no device needed).  out: HOST int64[k].
+ * Needs 1 <= k <= 64, k <= n, n <= 2^32; seed is the 32-bit seed (RandomState rejects larger ones).  Allocates 4 n bytes
+ * of scratch on the host for the call. */
+int mcr_sample_columns(uint32_t seed, uint64_t n, int32_t k, int64_t* out);
 /* stream_payment_start_month_index (simulation.py:47-63). */
 int32_t mcr_stream_start_month_index(double current_age, int32_t working_months, double start_at_age);
 

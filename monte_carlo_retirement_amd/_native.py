@@ -203,6 +203,7 @@ ABI_SYMBOLS = (
     "mcr_run_batch_multi_host_rng",
     "mcr_validate_params",
     "mcr_release_cached",
+    "mcr_sample_columns",
     "mcr_eval_helper_host",
     "mcr_row_quantiles_scratch_bytes",
     "mcr_row_quantiles",
@@ -279,6 +280,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.mcr_validate_params.argtypes = [P(McrParams)]
     lib.mcr_release_cached.restype = C.c_int
     lib.mcr_release_cached.argtypes = [C.c_int]
+    lib.mcr_sample_columns.restype = C.c_int
+    lib.mcr_sample_columns.argtypes = [C.c_uint32, C.c_uint64, C.c_int32, C.c_void_p]
     lib.mcr_draw_shocks_host_rng.restype = C.c_int
     lib.mcr_draw_shocks_host_rng.argtypes = [
         P(McrRng), C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_double, C.c_void_p, C.c_int,

@@ -1355,6 +1355,57 @@ int mcr_run_batch_multi_host_rng(const mcr_params* p, const mcr_rng* rng, uint32
 
 int mcr_validate_params(const mcr_params* p) { return validate_params(p); }
 
+// numpy.random.RandomState(seed).choice(n, k, replace=False) without shuffling an n-element array (include/mcr.h).
+// MT19937 as NumPy's legacy generator runs it: init_genrand seeding (numpy/random/src/mt19937/mt19937.c: mt19937_seed),
+// tempered 32-bit outputs, bounded draws by masked rejection (legacy-distributions.c: legacy_random_interval ->
+// random_interval), Fisher-Yates from i = n - 1 down to 1 (_mt19937 / mtrand.pyx: _shuffle_raw).
+int mcr_sample_columns(uint32_t seed, uint64_t n, int32_t k, int64_t* out) {
+    if (!out || k < 1 || k > 64 || (uint64_t)k > n || n > ((uint64_t)1 << 32)) { set_error("mcr_sample_columns: need 1 <= k <= min(n, 64), n <= 2^32"); return MCR_ERR_INVALID_ARG; }
+    uint32_t mt[624];
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int pos = 624;
+    auto regenerate = [&]() {
+        constexpr uint32_t kUpper = 0x80000000u, kLower = 0x7fffffffu, kMatrix = 0x9908b0dfu;
+        int i = 0;
+        for (; i < 624 - 397; ++i) { const uint32_t y = (mt[i] & kUpper) | (mt[i + 1] & kLower); mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u); }
+        for (; i < 623; ++i) { const uint32_t y = (mt[i] & kUpper) | (mt[i + 1] & kLower); mt[i] = mt[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u); }
+        const uint32_t y = (mt[623] & kUpper) | (mt[0] & kLower);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? kMatrix : 0u);
+        pos = 0;
+    };
+    auto next32 = [&]() -> uint32_t {
+        if (pos == 624) regenerate();
+        uint32_t y = mt[pos++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    };
+    if (n == 1) { out[0] = 0; return MCR_OK; }
+    // J[i] = the partner position drawn at step i (i = n - 1 ... 1); J[0] unused
+    uint32_t* J = (uint32_t*)std::malloc((size_t)n * sizeof(uint32_t));
+    if (!J) { set_error("mcr_sample_columns: out of host memory (%llu bytes)", (unsigned long long)(n * 4)); return MCR_ERR_INVALID_ARG; }
+    for (uint64_t i = n - 1; i >= 1; --i) {
+        uint64_t mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = next32() & (uint32_t)mask; } while ((uint64_t)v > i);   // (i <= 2^32 - 1: the 32-bit branch of random_interval)
+        J[i] = v;
+    }
+    // the value that ends at position p started at the position found by undoing the swaps, last one first
+    uint32_t where[64];
+    for (int p = 0; p < k; ++p) where[p] = (uint32_t)p;
+    for (uint64_t i = 1; i < n; ++i) {
+        const uint32_t j = J[i], ii = (uint32_t)i;
+        for (int p = 0; p < k; ++p) {
+            const uint32_t w = where[p];
+            where[p] = w == ii ? j : (w == j ? ii : w);
+        }
+    }
+    std::free(J);
+    for (int p = 0; p < k; ++p) out[p] = (int64_t)where[p];
+    return MCR_OK;
+}
+
 int mcr_release_cached(int device) {
     std::vector<HostCtx*> ctxs;
     std::vector<StreamFork*> forks;

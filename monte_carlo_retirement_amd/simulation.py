@@ -152,6 +152,24 @@ def _summary_frame(batch, n: int) -> pd.DataFrame:
     return pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS}, copy=False)
 
 
+def sample_columns(seed: int, n: int, k: int):
+    """``numpy.random.RandomState(seed).choice(n, k, replace=False)`` — the column indices pandas' ``DataFrame.sample(n=k,
+    axis=1, random_state=seed)`` picks (simulation.py:1063-1078) — or None (error logged) where NumPy raises, as the
+    reference does (:1079-1083; e.g. seed >= 2**32).  NumPy shuffles all n indices for it; the library's restatement
+    (``mcr_sample_columns``: same MT19937 draws, the k positions traced back through the swaps) returns the same indices in
+    about half the time — it has to hide under a kernel launch of n paths."""
+    if 0 <= int(seed) < 2**32 and 1 <= k <= 64 and k <= n <= 2**32:
+        out = np.empty(k, dtype=np.int64)
+        rc = N.load_library().mcr_sample_columns(int(seed), int(n), int(k), out.ctypes.data)
+        if rc == 0:
+            return out
+    try:
+        return np.random.RandomState(seed).choice(int(n), size=int(k), replace=False)
+    except ValueError as ve:
+        logger.error(f"Error sampling trajectories: {ve}")
+        return None
+
+
 def _fold_seed_u64(seed: int) -> int:
     """Philox key = the seed folded to 64 bits (seeds are unbounded Python ints in the Config)."""
     s, out = int(seed), 0
@@ -427,11 +445,7 @@ class RetirementMonteCarloSimulator:
         k = min(int(n), 5)
         if k <= 0:
             return None
-        try:
-            return np.random.RandomState(self.main_seed).choice(int(n), size=k, replace=False)
-        except ValueError as ve:
-            logger.error(f"Error sampling trajectories: {ve}")
-            return None
+        return sample_columns(self.main_seed, int(n), k)
 
     def _run_sharded(self, wm: int, n: int):
         """run_monte_carlo_simulations with one process per GPU (torch.distributed initialised): every rank

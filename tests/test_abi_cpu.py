@@ -157,3 +157,31 @@ def test_plain_c_caller_compiles_and_fails_loudly_without_a_gpu(lib, tmp_path):
         pytest.skip("a GPU is present (the run itself is tests/test_gpu_edge_cases.py)")
     r = subprocess.run([exe, "1000"], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
+
+
+def test_sample_columns_equals_numpy_randomstate_choice(lib):
+    """`mcr_sample_columns` restates RandomState(seed).choice(n, k, replace=False) — what pandas' sample(n=5, axis=1,
+    random_state=main_seed) draws in the reference (simulation.py:1063-1078) — without shuffling n indices: the same
+    MT19937 draws, the k positions traced back through the swaps.  Host-only; must equal NumPy on every input."""
+    from monte_carlo_retirement_amd.simulation import sample_columns
+
+    rng = np.random.default_rng(20261004)
+    cases = [(0, 1, 1), (0, 2, 2), (2**32 - 1, 5, 5), (12345, 64, 64), (7, 65, 64), (99, 2**16, 5), (99, 2**16 + 1, 5), (1, 2**20 - 1, 3)]
+    for _ in range(400):
+        n = int(rng.choice([1, 2, 3, 5, 6, 7, 63, 64, 65, 1000, 4096, 65537, int(rng.integers(5, 400_000))]))
+        cases.append((int(rng.integers(0, 2**32)), n, min(n, int(rng.integers(1, 9)))))
+    for seed, n, k in cases:
+        got = sample_columns(seed, n, k)
+        exp = np.random.RandomState(seed).choice(n, size=k, replace=False)
+        assert got.dtype == np.int64 and np.array_equal(got, exp), (seed, n, k, got, exp)
+    # the scenario files' shape: 5 of 10^6 for the seeds the tests and the bench use
+    for seed in (12345, 2024, 99):
+        assert np.array_equal(sample_columns(seed, 1_000_000, 5), np.random.RandomState(seed).choice(1_000_000, size=5, replace=False))
+    # outside the restatement's domain: NumPy's own path (more than 64 picks) or NumPy's own error (seed >= 2**32 -> None, logged)
+    assert np.array_equal(sample_columns(5, 1000, 100), np.random.RandomState(5).choice(1000, size=100, replace=False))
+    assert sample_columns(2**32, 1000, 5) is None
+    assert sample_columns(5, 3, 5) is None                      # more picks than paths: NumPy raises, the reference logs
+    out = (C.c_int64 * 4)()
+    for seed, n, k in ((1, 10, 0), (1, 10, 65), (1, 3, 4), (1, 2**32 + 1, 2)):
+        assert lib.mcr_sample_columns(seed, n, k, out) == -1 and "mcr_sample_columns" in N.last_error()
+    assert lib.mcr_sample_columns(1, 10, 2, None) == -1
