@@ -616,7 +616,7 @@ def main():
                 "devices": devices_seen,           # every rank's own report (all_gather_object)
             },
             "roofline": {
-                "kernel": "mcr::path_kernel<0, 0, true, false, false, 0>  (MODE 0 count-only, Philox, realized-gains tax, no annual tax)",
+                "kernel": "mcr::path_kernel<0, 0, 3, false, false, 0, false>  (MODE 0 count-only, Philox, realized-gains tax on both assets, no annual tax, unsplit)",
                 "bound": "valu_fp64",
                 "achieved": achieved_t,
                 "peak": FP64_LANE_OPS_PEAK_T,

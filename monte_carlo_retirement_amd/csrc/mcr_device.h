@@ -49,7 +49,8 @@ struct DevParams {
     int32_t num_working_years, trajectory_len, n_streams, n_lock_slots;
     int32_t contrib_grows;             // contribution_growth_rate_annual > 0        (:516)
     int32_t any_annual_tax;            // annual_rate1 > 0 || annual_rate2 > 0
-    int32_t any_real_rate;             // real_rate1 > 0 || real_rate2 > 0  -> selects the TAXED kernel variant
+    int32_t any_real_rate;             // real_rate1 > 0 || real_rate2 > 0
+    int32_t tax_mask;                  // bit 0: real_rate1 > 0, bit 1: real_rate2 > 0  -> selects the TAXED kernel variant (0 .. 3)
     DevStream streams[MCR_MAX_STREAMS];
 };
 
@@ -306,14 +307,15 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
 // Path form of TWO independent evaluations of the same helper (the two assets of one month): all the arithmetic of
 // both first — two independent dependency chains the scheduler can interleave —, then the exec-masked fix-ups
 // (each branch ends a basic block; placed between the two chains they would serialise them).
-template <bool TAXED>
+// (T1 / T2: does asset 1 / 2 carry an effective realized-gains rate?  Per asset since round 3: the reference's DEFAULT
+//  configuration taxes realized gains on inv2 only, config.py:74-75,80-81 — with a rate of exactly 0 every product with it is
+//  +0 and t / 1 = t, so the untaxed form of ONE asset is bit-identical too and skips its dead divisions.)
+template <bool T1, bool T2 = T1>
 __device__ __forceinline__ void net_liquidation_values2(double b1, double c1, double r1, double b2, double c2, double r2,
                                                         double& v1, double& v2) {
     v1 = b1; v2 = b2;
-    if (TAXED) {
-        const double t1 = fmax(0.0, b1 - c1) * r1, t2 = fmax(0.0, b2 - c2) * r2;
-        v1 = b1 - t1; v2 = b2 - t2;                              // tax <= bal when cb >= 0, rate <= 1
-    }
+    if (T1) v1 = b1 - fmax(0.0, b1 - c1) * r1;                   // tax <= bal when cb >= 0, rate <= 1
+    if (T2) v2 = b2 - fmax(0.0, b2 - c2) * r2;
     if (b1 <= kEps) { asm volatile(""); v1 = 0.0; }
     if (b2 <= kEps) { asm volatile(""); v2 = 0.0; }
 }
@@ -351,11 +353,11 @@ __device__ __forceinline__ void withdraw_fixup(WithdrawCand& w, double& bal, dou
     }
     bal = w.nb; cb = w.ncb; gross_out = w.gross; net_out = w.net;
 }
-template <bool TAXED>
+template <bool T1, bool T2 = T1>
 __device__ __forceinline__ void withdraw2(double& b1, double& c1, double t1, double r1, double& g1, double& n1,
                                           double& b2, double& c2, double t2, double r2, double& g2, double& n2) {
-    WithdrawCand w1 = withdraw_arith<TAXED>(b1, c1, t1, r1);
-    WithdrawCand w2 = withdraw_arith<TAXED>(b2, c2, t2, r2);
+    WithdrawCand w1 = withdraw_arith<T1>(b1, c1, t1, r1);
+    WithdrawCand w2 = withdraw_arith<T2>(b2, c2, t2, r2);
     withdraw_fixup(w1, b1, c1, t1, g1, n1);
     withdraw_fixup(w2, b2, c2, t2, g2, n2);
 }
@@ -478,7 +480,7 @@ __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
 // ANNUAL = false: compile-time variant for scenarios in which no asset is on the annual-gains system (annual
 // bill identically 0, :380-390): the block below and the monthly gain accumulators are dead code.
-template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true>
+template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true, bool T1 = TAXED, bool T2 = TAXED>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
@@ -486,8 +488,8 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
         const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
         const double total_due = due1 + due2;                         // :390
-        const double cap1 = net_liquidation_value<STRICT, TAXED>(b1, c1, L.real_rate1);  // :392-397
-        const double cap2 = net_liquidation_value<STRICT, TAXED>(b2, c2, L.real_rate2);  // :398-403
+        const double cap1 = net_liquidation_value<STRICT, T1>(b1, c1, L.real_rate1);  // :392-397
+        const double cap2 = net_liquidation_value<STRICT, T2>(b2, c2, L.real_rate2);  // :398-403
         const double cap = cap1 + cap2;                               // :404
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
@@ -495,8 +497,8 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
             const double share1 = fdiv<STRICT>(cap1, cap);            // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
-            withdraw<STRICT, TAXED>(b1, c1, pay * share1, L.real_rate1, g, net1);  // :411-419
-            withdraw<STRICT, TAXED>(b2, c2, pay * share2, L.real_rate2, g, net2);  // :420-428
+            withdraw<STRICT, T1>(b1, c1, pay * share1, L.real_rate1, g, net1);  // :411-419
+            withdraw<STRICT, T2>(b2, c2, pay * share2, L.real_rate2, g, net2);  // :420-428
             tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
         }
     }

@@ -88,10 +88,13 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // halves of a month's dependency chain then run on different SIMDs of the CU.  One workgroup barrier per pair of months
 // hands a buffer over; every wave executes the same number of them (no early exit when all lanes have failed) or has
 // terminated.  The arithmetic of every path is unchanged: counts are bit-identical to SPLIT = false.
-template <int MODE, int RNG, bool TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false>
+template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
+    // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
+    static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
+    constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
     constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
     const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
     const bool producer = SPLIT && threadIdx.x >= (unsigned)kBlock;                  // wave-uniform (kBlock = 4 wavefronts)
@@ -293,9 +296,9 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance_path<TAXED>(L, b1, c1, b2, c2);                      // :549-553
+        rebalance_path<TANY>(L, b1, c1, b2, c2);                       // :549-553
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes<false, TANY, ANNUAL, T1, T2>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                 }
                 if (!stop) {
                     double cap1, cap2;
-                    net_liquidation_values2<TAXED>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
+                    net_liquidation_values2<T1, T2>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmin(need, cap);                            // :739-742 (need, cap >= 0: the max(0, .) is a no-op)
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
@@ -367,15 +370,15 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     if (!(cap > kEps)) { asm volatile(""); prop1 = P.alloc1; }        // (exec-masked move, not a select)
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
-                    withdraw2<TAXED>(b1, c1, target * prop1, L.real_rate1, gw1, nw1,   // :757-765
+                    withdraw2<T1, T2>(b1, c1, target * prop1, L.real_rate1, gw1, nw1,  // :757-765
                                      b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg1 += gw1;                                                       // :766
                     tg2 += gw2;                                                       // :777
                     if (kSummary) treal += fdiv<false>((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance_path<TAXED>(L, b1, c1, b2, c2);                         // :792-796
+                    rebalance_path<TANY>(L, b1, c1, b2, c2);                          // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
-                        const bool tf = annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
                         yfail = yfail || tf;                                          // :821-822
                     }
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes<false, TAXED, ANNUAL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
             if (tf) {                                                            // :894-896
                 succeeded = false; ruin_bin = ry + 1;
                 if (kSumLds) sum_col[2 * kBlock] = (double)ry; else ytr_bits = f64_bits((double)ry);
@@ -546,8 +549,12 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
             const double* x = in + 6 * i;
             const LaneParams L = lane_params(P);
             double b1 = x[0], c1 = x[1], b2 = x[3], c2 = x[4], g1, n1, g2, n2;
-            if (P.any_real_rate) withdraw2<true>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2);
-            else withdraw2<false>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2);
+            switch (P.tax_mask) {   // the per-asset forms the path kernel runs for this parameter block
+                case 0: withdraw2<false, false>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2); break;
+                case 1: withdraw2<true, false>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2); break;
+                case 2: withdraw2<false, true>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2); break;
+                default: withdraw2<true, true>(b1, c1, x[2], L.real_rate1, g1, n1, b2, c2, x[5], L.real_rate2, g2, n2); break;
+            }
             double* o = out + 8 * i;
             o[0] = b1; o[1] = c1; o[2] = g1; o[3] = n1; o[4] = b2; o[5] = c2; o[6] = g2; o[7] = n2;
             break;
@@ -556,8 +563,12 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
             const double* x = in + 4 * i;
             const LaneParams L = lane_params(P);
             double v1, v2;
-            if (P.any_real_rate) net_liquidation_values2<true>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2);
-            else net_liquidation_values2<false>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2);
+            switch (P.tax_mask) {
+                case 0: net_liquidation_values2<false, false>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2); break;
+                case 1: net_liquidation_values2<true, false>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2); break;
+                case 2: net_liquidation_values2<false, true>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2); break;
+                default: net_liquidation_values2<true, true>(x[0], x[1], L.real_rate1, x[2], x[3], L.real_rate2, v1, v2); break;
+            }
             out[2 * i] = v1; out[2 * i + 1] = v2;
             break;
         }
@@ -574,10 +585,15 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
             double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
             const LaneParams L = lane_params(P);
             bool tf;
-            if (P.any_real_rate) tf = P.any_annual_tax ? annual_gain_taxes<false, true, true>(P, L, b1, c1, b2, c2, x[4], x[5])
-                                                       : annual_gain_taxes<false, true, false>(P, L, b1, c1, b2, c2, x[4], x[5]);
-            else tf = P.any_annual_tax ? annual_gain_taxes<false, false, true>(P, L, b1, c1, b2, c2, x[4], x[5])
-                                       : annual_gain_taxes<false, false, false>(P, L, b1, c1, b2, c2, x[4], x[5]);
+#define MCR_ATAX(T1_, T2_) (P.any_annual_tax ? annual_gain_taxes<false, (T1_) || (T2_), true, T1_, T2_>(P, L, b1, c1, b2, c2, x[4], x[5]) \
+                                             : annual_gain_taxes<false, (T1_) || (T2_), false, T1_, T2_>(P, L, b1, c1, b2, c2, x[4], x[5]))
+            switch (P.tax_mask) {
+                case 0: tf = MCR_ATAX(false, false); break;
+                case 1: tf = MCR_ATAX(true, false); break;
+                case 2: tf = MCR_ATAX(false, true); break;
+                default: tf = MCR_ATAX(true, true); break;
+            }
+#undef MCR_ATAX
             out[5 * i + 0] = b1; out[5 * i + 1] = c1; out[5 * i + 2] = b2; out[5 * i + 3] = c2;
             out[5 * i + 4] = tf ? 1.0 : 0.0;
             break;
@@ -866,6 +882,10 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     d->annual_rate2 = !p->inv2_use_realized_gains_tax_system ? p->inv2_annual_tax_on_gains_rate : 0.0;  // :385-389
     d->any_annual_tax = (d->annual_rate1 > 0.0) || (d->annual_rate2 > 0.0);
     d->any_real_rate = (d->real_rate1 > 0.0) || (d->real_rate2 > 0.0);
+    d->tax_mask = (d->real_rate1 > 0.0 ? 1 : 0) | (d->real_rate2 > 0.0 ? 2 : 0);
+#ifdef MCR_K1_COARSE_TAX   // (A/B builds only: round 2's taxed / untaxed variants)
+    if (d->tax_mask) d->tax_mask = 3;
+#endif
     const double sqrt12 = std::sqrt((double)kMPY);
     d->a1 = p->inv1_mu_log / (double)kMPY;   d->b1 = p->inv1_sigma_log / sqrt12;     // :473
     d->ainf = p->inf_mu_log / (double)kMPY;  d->binf = p->inf_sigma_log / sqrt12;
@@ -979,18 +999,25 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     if (split) {
         const dim3 block2(2 * kBlock);
 #define MCR_LAUNCH_S(T, A) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 0, true>), grid, block2, lds, stream, d, io, (const DevParams*)nullptr)
-        if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH_S(true, true); else MCR_LAUNCH_S(true, false); }
-        else { if (d.any_annual_tax) MCR_LAUNCH_S(false, true); else MCR_LAUNCH_S(false, false); }
+#define MCR_LAUNCH_SA(T) do { if (d.any_annual_tax) MCR_LAUNCH_S(T, true); else MCR_LAUNCH_S(T, false); } while (0)
+        switch (d.tax_mask) { case 0: MCR_LAUNCH_SA(0); break; case 1: MCR_LAUNCH_SA(1); break; case 2: MCR_LAUNCH_SA(2); break; default: MCR_LAUNCH_SA(3); break; }
+#undef MCR_LAUNCH_SA
 #undef MCR_LAUNCH_S
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return hip_fail(es, "path_kernel launch (split)");
         return MCR_OK;
     }
 #define MCR_LAUNCH(M, R, T, A, I) hipLaunchKernelGGL((path_kernel<M, R, T, A, I>), grid, block, lds, stream, d, io, (const DevParams*)nullptr)
+    // the engine's own stream: one variant per tax mask (which of the two assets is taxed on realized gains); the parity
+    // hook and the NumPy stream: taxed / untaxed only (mask 3 computes a zero-rate asset's tax arithmetic as exact zeros)
+#define MCR_LAUNCH_A(M, R, T, I) do { if (d.any_annual_tax) MCR_LAUNCH(M, R, T, true, I); else MCR_LAUNCH(M, R, T, false, I); } while (0)
 #define MCR_LAUNCH_T(M, R, I)                                                                      \
     do {                                                                                           \
-        if (d.any_real_rate) { if (d.any_annual_tax) MCR_LAUNCH(M, R, true, true, I); else MCR_LAUNCH(M, R, true, false, I); } \
-        else { if (d.any_annual_tax) MCR_LAUNCH(M, R, false, true, I); else MCR_LAUNCH(M, R, false, false, I); }               \
+        if (R == 0 && !I) {                                                                        \
+            switch (d.tax_mask) { case 0: MCR_LAUNCH_A(M, 0, 0, false); break; case 1: MCR_LAUNCH_A(M, 0, 1, false); break; \
+                                  case 2: MCR_LAUNCH_A(M, 0, 2, false); break; default: MCR_LAUNCH_A(M, 0, 3, false); break; } \
+        } else if (d.any_real_rate) MCR_LAUNCH_A(M, R, 3, I);                                       \
+        else MCR_LAUNCH_A(M, R, 0, I);                                                              \
     } while (0)
     if (injected) {
         MCR_LAUNCH_T(2, 0, true);
@@ -1004,6 +1031,7 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
         else MCR_LAUNCH_T(0, 1, false);
     }
 #undef MCR_LAUNCH_T
+#undef MCR_LAUNCH_A
 #undef MCR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "path_kernel launch");
@@ -1105,8 +1133,9 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
             if (split2) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2, true>), g2, block2, lds, stream, top, io, d_blocks); \
             else hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2>), g2, block, lds, stream, top, io, d_blocks);    \
         } while (0)
-        if (top.any_real_rate) { if (top.any_annual_tax) MCR_PHASES(true, true); else MCR_PHASES(true, false); }
-        else { if (top.any_annual_tax) MCR_PHASES(false, true); else MCR_PHASES(false, false); }
+#define MCR_PHASES_A(T) do { if (top.any_annual_tax) MCR_PHASES(T, true); else MCR_PHASES(T, false); } while (0)
+        switch (top.tax_mask) { case 0: MCR_PHASES_A(0); break; case 1: MCR_PHASES_A(1); break; case 2: MCR_PHASES_A(2); break; default: MCR_PHASES_A(3); break; }
+#undef MCR_PHASES_A
 #undef MCR_PHASES
         e = hipGetLastError();
     }
