@@ -88,7 +88,9 @@ _pinned = threading.local()
 
 
 def _pinned_result(n_doubles: int):
-    """A pinned (page-locked, device-visible) float64 host buffer of at least `n_doubles`, cached per calling thread."""
+    """A pinned (page-locked, device-visible) float64 host buffer of at least `n_doubles`, cached per calling thread.
+    (torch pins with hipHostMalloc's default flags: coherent host memory, so what the kernels wrote is visible to the host
+    once the stream has been synchronised.)"""
     import torch
 
     buf = getattr(_pinned, "buf", None)
