@@ -213,7 +213,9 @@ def success_histogram(values, success, n_bins: int = 100, value_range: Optional[
     dev = values.device
     n = int(values.shape[0])
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    minmax = torch.empty(2, dtype=torch.float64, device=dev)
+    # range and bins share ONE device buffer (2 doubles | n_bins int64): one download and one synchronisation at the end
+    both = torch.zeros(2 + n_bins, dtype=torch.int64, device=dev)
+    minmax, bins = both[:2].view(torch.float64), both[2:]
     if value_range is None:
         N.check(lib.mcr_minmax_success(values.data_ptr(), success.data_ptr(), n, minmax.data_ptr(), dev.index or 0, stream),
                 "mcr_minmax_success")
@@ -221,17 +223,17 @@ def success_histogram(values, success, n_bins: int = 100, value_range: Optional[
             reduce_range(minmax)
     else:
         minmax.copy_(torch.tensor(value_range, dtype=torch.float64))
-    bins = torch.zeros(n_bins, dtype=torch.int64, device=dev)
     N.check(lib.mcr_histogram_success(values.data_ptr(), success.data_ptr(), n, minmax.data_ptr(), n_bins,
                                       bins.data_ptr(), dev.index or 0, stream), "mcr_histogram_success")
     if reduce_bins is not None:
         reduce_bins(bins)
-    lo, hi = (float(x) for x in minmax.cpu().tolist())
+    host = both.cpu()
+    lo, hi = (float(x) for x in host[:2].view(torch.float64).tolist())
     if not np.isfinite(lo) or not np.isfinite(hi):  # empty cohort: numpy's default range
         lo, hi = 0.0, 1.0
     if lo == hi:
         lo, hi = lo - 0.5, hi + 0.5
-    return bins.cpu().numpy(), np.linspace(lo, hi, n_bins + 1)
+    return host[2:].numpy().copy(), np.linspace(lo, hi, n_bins + 1)
 
 
 def summary_stat_rows(batch, n: int):
