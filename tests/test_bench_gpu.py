@@ -148,3 +148,21 @@ def test_launcher_deadline_kills_hung_ranks_and_reports(tmp_path):
     assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
     assert "overall deadline reached" in r.stderr and "killing ranks [0, 1]" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver's own command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (ranks from the environment, no self-launch) — here
+    with N = 2 on the box's one GPU and the gloo backend."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--paths", "200000", "--s60-paths", "300001", "--no-search", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints, rank 1 does not
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["paths_counted"] == 2 * 3 * 200000
+    assert out["s60"]["exchange"].startswith("1 all-reduce(sum)") and "search" not in out and "cpu_baseline" not in out
