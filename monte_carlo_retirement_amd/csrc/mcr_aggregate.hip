@@ -1880,6 +1880,7 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     for (int j = 0; j < n_q; ++j) a.q[j] = q[j];
     rq_opt_in_lds(device);
     int64_t m = n / 32;           // the second sample: the first n/32 entries of every row
+    if (const char* e = std::getenv("MCR_RQ_SAMPLE_DIV")) { const int t = std::atoi(e); if (t >= 2) m = n / t; }
     if (m < 65536) m = 65536;
     if (m > n) m = n;
     m &= ~(int64_t)1;
