@@ -181,11 +181,17 @@ def aux_hbm_kernels(torch, n):
         "K3_row_quantiles": {"ms": ms_k3, "by_allocation_ms": k3_by_alloc, "rows": 2 * T + ry, "algorithmic_read_bytes": bytes_k3,
                              "GBps": bytes_k3 / ms_k3 / 1e6, "frac_of_hbm_peak": bytes_k3 / ms_k3 / 1e6 / HBM_PEAK_GBS,
                              "fallback_rows": fallback_rows, "slab_pass_profiled": profiled,
+                             # STATIC, from a committed microbenchmark run (tools/ubench/hbm_read.hip), not measured here: what this part's
+                             # memory system gives a kernel of the slab pass's shape
+                             "memory_system_measured": {"read_only_sweep_TBps": [6.5, 7.0], "read_sweep_with_4pct_writes_TBps": [4.9, 5.6],
+                                                        "slab_pass_without_candidate_output_TBps": [6.6, 6.8],
+                                                        "source": "profiles/r03/hbm_read_gfx950.txt, profiles/r03/k3_slab_parts.txt"},
                              "note": "one call over the [2T+ry] slab (bands of all rows), steady state (3 warm-up calls, median of 15; `ms` = the "
                                      "median over three allocations of the batch, `by_allocation_ms` lists them): seven "
                                      "launches + one word read back, results written straight into pinned host memory. Algorithmic bytes = ONE read "
                                      "of the slab; the pass that does it (rq_slab_kernel) runs at 5.3-6.0 TB/s depending on where the driver placed "
-                                     "this process's slab (DESIGN.md 5), the rest is the two sampling steps before it and the per-row cell selection "
+                                     "this process's slab (DESIGN.md 5) - the rate a bare read sweep with the pass's 4 % of candidate writes reaches "
+                                     "on this part (`memory_system_measured`; reading alone: 6.5-7.0) -, the rest is the two sampling steps before it and the per-row cell selection "
                                      "after it (profiles/). fallback_rows = rows that needed the 4-pass radix select (-1: rows too short for the "
                                      "bracketed route)"},
         "K2_histogram": {"ms": ms_k2, "algorithmic_bytes": bytes_k2, "GBps": bytes_k2 / ms_k2 / 1e6},
