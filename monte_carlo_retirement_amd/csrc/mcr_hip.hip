@@ -315,6 +315,17 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     bool succeeded = !pre_fail;
     unsigned long long ytr_bits = pre_fail ? f64_bits(0.0) : kNanBits;  // YearsToRuin (:497, :628-629)
     if (kSumLds) { sum_col[0] = 0.0; sum_col[kBlock] = 0.0; store_bits(&sum_col[2 * kBlock], ytr_bits); }
+    // A launch that cannot fill the chip (SPLIT) is bound by each wave's dependency chain, and re-reading a stream's record
+    // from the kernel arguments every month is three dependent scalar loads on it (the compiler loads start, then end, then
+    // the rest): the first two records stay in SGPRs there (82 + 16 of them; the unsplit kernel has none to spare).
+    DevStream S0 = {}, S1 = {};
+    if (SPLIT) {
+        if (P.n_streams > 0) S0 = P.streams[0];
+        if (P.n_streams > 1) S1 = P.streams[1];
+        // (opaque to the compiler from here on: kernel-argument loads are otherwise rematerialised in the loop)
+        asm volatile("" : "+s"(S0.amount), "+s"(S0.keep), "+s"(S0.start_month), "+s"(S0.end_month), "+s"(S0.indexed), "+s"(S0.lock_slot));
+        asm volatile("" : "+s"(S1.amount), "+s"(S1.keep), "+s"(S1.start_month), "+s"(S1.end_month), "+s"(S1.indexed), "+s"(S1.lock_slot));
+    }
     int ruin_bin = pre_fail ? 0 : -1;
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
@@ -333,9 +344,8 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                 const double price = infl;                             // :644
                 const double expenses = P.monthly_expenses * price;    // :645-647
                 double income = 0.0;                                   // :649
-                for (int s = 0; s < P.n_streams; ++s) {                // :650 (wave-uniform)
-                    const DevStream S = P.streams[s];                  // one 32-byte scalar load per stream, not five dependent ones
-                    if (rmi < S.start_month || rmi >= S.end_month) continue;  // :653-658
+                auto stream_income = [&](const DevStream& S) {
+                    if (rmi < S.start_month || rmi >= S.end_month) return;    // :653-658
                     double nominal;
                     if (S.indexed) {
                         nominal = S.amount * price;                    // :661-665
@@ -345,7 +355,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                         nominal = *slot;                               // :672-674
                     }
                     income += nominal * S.keep;                        // :675-677
+                };
+                int s = 0;
+                if (SPLIT) {            // the first two streams sit in SGPRs for the whole launch (see S0, S1 above)
+                    if (P.n_streams > 0) stream_income(S0);
+                    if (P.n_streams > 1) stream_income(S1);
+                    s = 2;
                 }
+                for (; s < P.n_streams; ++s) stream_income(P.streams[s]);    // :650 (wave-uniform; the record is re-read from the kernel arguments)
                 const double need = fmax(0.0, expenses - income);      // :679-682
                 bool stop = false;
                 if (b1 + b2 <= kEps && need > kEps) {                  // :684-690 (FAIL-1, no shock consumed)
