@@ -625,6 +625,9 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
     if (t == 0) { rq_make_intervals(B, qlo, qhi, args.n_q, kRqCoarseSubBits); B.open_lo = open_lo; B.open_hi = open_hi; }
 }
 
+#ifdef MCR_RQ_EXPERIMENT
+__device__ double g_rq_sigmas = 4.5;   // timing experiments only: narrower fine brackets = fewer candidates (rows may then take the radix route)
+#endif
 struct RqRefineShared {
     unsigned long long below[kRqMaxQ], upto[kRqMaxQ], qlo[kRqMaxQ], qhi[kRqMaxQ];
     unsigned int miss;
@@ -1088,7 +1091,11 @@ __device__ void rq_refine_row(int row, int64_t m, const RqArgs& args, const RqBr
         } else {
             const double q = args.q[t];
             const double vi = (double)(mv - 1) * q;
+#ifdef MCR_RQ_EXPERIMENT
+            const double d = ceil(g_rq_sigmas * sqrt((double)mv * q * (1.0 - q))) + 2.0;   // (experiment: MCR_RQ_SIGMAS)
+#else
             const double d = ceil(kRqBracketSigmas * sqrt((double)mv * q * (1.0 - q))) + 2.0;
+#endif
             const double rl = floor(vi) - d, rh = floor(vi) + 1.0 + d;
             const int b = B1.interval_of_q[t];
             const unsigned long long lo_b = B1.lo[b], hi_b = B1.hi[b];
@@ -1922,6 +1929,9 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     //  one process: G = 1 2.262 ms, G = 2 2.345, G = 3 2.478, G = 4 2.717 — cross-stream event waits cost more than the
     //  0.35 ms of small kernels they were meant to hide.)
     hipError_t e = hipSuccess;
+#ifdef MCR_RQ_EXPERIMENT
+    { const char* e = std::getenv("MCR_RQ_SIGMAS"); const double sg = e ? std::atof(e) : 4.5; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rq_sigmas), &sg, sizeof(sg), 0, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); }
+#endif
     head(s, 0, n_rows, L.fb_count);
     slab(s, 0, n_rows);
 #ifdef MCR_RQ_EXPERIMENT

@@ -5,7 +5,8 @@ kernel's duration per setting, interleaved over rounds on ONE allocation of the 
 
     MCR_HIP_LIBRARY=.../libmcr_hip_exp.so python tools/k3_slab_parts.py 10000000 0 1 2 4 8 16 ...
 bits: 1 no staging of bracket members, 2 flush without the global atomic + candidate stores, 4 flush without the
-sub-histogram tally, 8 no position counters (ds_add), 16 no bucket table / bound pair (position = one compare)
+sub-histogram tally, 32 flush without the stores, 64 flush without the atomic, 128 nontemporal candidate stores (a valid pass),
+256 nothing switched off, but the call returns after the slab pass (use with narrowed brackets, e.g. 256:1.6)
 """
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ from monte_carlo_retirement_amd import Config, params_from_config
 from monte_carlo_retirement_amd import aggregation as A, engine as E
 
 n = int(sys.argv[1])
-settings = [int(x) for x in sys.argv[2:]] or [0]
+settings = sys.argv[2:] or ["0"]      # "dbg" or "dbg:sigmas" (MCR_RQ_SIGMAS: half-width of the fine brackets, default 4.5)
 rounds = int(os.environ.get("K3_PARTS_ROUNDS", "5"))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = Config(**dict(json.load(open(os.path.join(root, "scenarios/jorge.json"))), equity_inflation_correlation=0.3, seed=12345))
@@ -24,9 +25,11 @@ os.environ["MCR_RQ_DBG"] = "0"
 for _ in range(6):
     A.band_quantiles(b, n)          # warm-up: scratch, clocks
 torch.cuda.synchronize()
-print("order", " ".join(str(s) for _ in range(rounds) for s in settings), flush=True)
+print("order", " ".join(s for _ in range(rounds) for s in settings), flush=True)
 for _ in range(rounds):
     for s in settings:
-        os.environ["MCR_RQ_DBG"] = str(s)
+        dbg, _, sig = s.partition(":")
+        os.environ["MCR_RQ_DBG"] = dbg
+        os.environ["MCR_RQ_SIGMAS"] = sig or "4.5"
         A.band_quantiles(b, n)
 torch.cuda.synchronize()

@@ -19,6 +19,6 @@ per = collections.defaultdict(list)
 for s, t in zip(order, slab):
     per[s].append(t)
 for s in dict.fromkeys(order):
-    print(f"dbg {int(s):3d}: median {statistics.median(per[s]):8.1f} us   min {min(per[s]):8.1f}   ({10.88e3 / statistics.median(per[s]):.3f} TB/s)   all {[round(x) for x in per[s]]}")
+    print(f"dbg {s:>8s}: median {statistics.median(per[s]):8.1f} us   min {min(per[s]):8.1f}   ({10.88e3 / statistics.median(per[s]):.3f} TB/s)   all {[round(x) for x in per[s]]}")
 PY
 find "$OUT" -name '*_kernel_trace.csv' -delete
