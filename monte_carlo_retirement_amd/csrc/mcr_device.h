@@ -18,6 +18,13 @@
 #include "../../include/mcr.h"
 #include "mcr_math.h"
 
+// `if (c) { MCR_MASKED_MOVE; x = y; }`: the empty asm keeps the assignment a BRANCH under the exec mask (v_cmp, s_and_saveexec,
+// moves, s_or) where the compiler would if-convert it into v_cndmask pairs — a 64-bit select costs two fp64 issue slots, the
+// masked move one and often none (§5 of DESIGN.md).  MM (a template parameter in scope at every use) = false leaves the
+// choice to the compiler: the producer / consumer SPLIT launches are bound by each wave's dependency chain, not by issue
+// slots, and there the compare -> scalar mask -> branch -> move round trip is the slower form (lone 50 000-path probe
+// 0.84 -> 0.79 ms, measured).  Same values either way.
+#define MCR_MASKED_MOVE do { if (MM) asm volatile(""); } while (0)
 namespace mcr {
 
 constexpr double kEps = MCR_SMALL_EPSILON;
@@ -247,7 +254,7 @@ constexpr int kStageDoubles = 6 * kBlock;   // 12 KB of LDS per workgroup
 // product with it is exactly +0, t / 1 = t, so the untaxed forms are bit-identical to the general ones and
 // skip the dead arithmetic (two of the three divisions in withdraw / rebalance): +13 % paths/s there.
 // (A run-time branch instead cost the taxed kernel 4 %, hence a template parameter.)
-template <bool STRICT = true, bool TAXED = true>
+template <bool STRICT = true, bool TAXED = true, bool MM = true>
 __device__ __forceinline__ double net_liquidation_value(double bal, double cb, double rate) {
     double v = bal;  // rate == 0: tax = 0, max(0, bal - 0) = bal for bal > eps
     if (TAXED) {
@@ -255,12 +262,12 @@ __device__ __forceinline__ double net_liquidation_value(double bal, double cb, d
         v = STRICT ? fmax(0.0, bal - tax) : bal - tax;  // tax <= bal when cb >= 0, rate <= 1
     }
     if (STRICT) return bal <= kEps ? 0.0 : v;
-    if (bal <= kEps) { asm volatile(""); v = 0.0; }   // path form: exec-masked move instead of a select (see withdraw)
+    if (bal <= kEps) { MCR_MASKED_MOVE; v = 0.0; }   // path form: exec-masked move instead of a select (see withdraw)
     return v;
 }
 
 // _calculate_withdrawal_and_update (:201-254): every lane evaluates the arithmetic; only the final selections differ by form.
-template <bool STRICT = true, bool TAXED = true>
+template <bool STRICT = true, bool TAXED = true, bool MM = true>
 __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_target, double rate,
                                          double& gross_out, double& net_out) {
     const bool skip = (bal <= kEps) || (net_target <= 0.0);              // :218
@@ -298,8 +305,8 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
         // each; a move under an exec mask costs about half of that, and the scalar mask bookkeeping is free next to
         // the VALU work.  (The empty asm keeps the compiler from converting the branches back into selects.)
         double rb = nb, rc = ncb, rg = gross, rn = net_cash;
-        if (dust) { asm volatile(""); rb = 0.0; rc = 0.0; }
-        if (skip) { asm volatile(""); rb = bal; rc = cb; rg = 0.0; rn = 0.0; }   // bal, cb >= 0 already
+        if (dust) { MCR_MASKED_MOVE; rb = 0.0; rc = 0.0; }
+        if (skip) { MCR_MASKED_MOVE; rb = bal; rc = cb; rg = 0.0; rn = 0.0; }   // bal, cb >= 0 already
         bal = rb; cb = rc; gross_out = rg; net_out = rn;
     }
 }
@@ -310,14 +317,14 @@ __device__ __forceinline__ void withdraw(double& bal, double& cb, double net_tar
 // (T1 / T2: does asset 1 / 2 carry an effective realized-gains rate?  Per asset since round 3: the reference's DEFAULT
 //  configuration taxes realized gains on inv2 only, config.py:74-75,80-81 — with a rate of exactly 0 every product with it is
 //  +0 and t / 1 = t, so the untaxed form of ONE asset is bit-identical too and skips its dead divisions.)
-template <bool T1, bool T2 = T1>
+template <bool T1, bool T2 = T1, bool MM = true>
 __device__ __forceinline__ void net_liquidation_values2(double b1, double c1, double r1, double b2, double c2, double r2,
                                                         double& v1, double& v2) {
     v1 = b1; v2 = b2;
     if (T1) v1 = b1 - fmax(0.0, b1 - c1) * r1;                   // tax <= bal when cb >= 0, rate <= 1
     if (T2) v2 = b2 - fmax(0.0, b2 - c2) * r2;
-    if (b1 <= kEps) { asm volatile(""); v1 = 0.0; }
-    if (b2 <= kEps) { asm volatile(""); v2 = 0.0; }
+    if (b1 <= kEps) { MCR_MASKED_MOVE; v1 = 0.0; }
+    if (b2 <= kEps) { MCR_MASKED_MOVE; v2 = 0.0; }
 }
 
 struct WithdrawCand { double nb, ncb, gross, net; };   // (the dust / skip tests are evaluated at the fix-up: a compare there
@@ -344,26 +351,27 @@ __device__ __forceinline__ WithdrawCand withdraw_arith(double bal, double cb, do
     w.ncb = cb - basis_removed;                                         // :244
     return w;
 }
+template <bool MM = true>
 __device__ __forceinline__ void withdraw_fixup(WithdrawCand& w, double& bal, double& cb, double net_target, double& gross_out,
                                                double& net_out) {
-    if (w.nb <= kEps) { asm volatile(""); w.nb = 0.0; w.ncb = 0.0; }                        // :245-247
+    if (w.nb <= kEps) { MCR_MASKED_MOVE; w.nb = 0.0; w.ncb = 0.0; }                        // :245-247
     if ((bal <= kEps) || (net_target <= 0.0)) {                                             // :218
-        asm volatile("");
+        MCR_MASKED_MOVE;
         w.nb = bal; w.ncb = cb; w.gross = 0.0; w.net = 0.0;                                 // bal, cb >= 0 already (:219)
     }
     bal = w.nb; cb = w.ncb; gross_out = w.gross; net_out = w.net;
 }
-template <bool T1, bool T2 = T1>
+template <bool T1, bool T2 = T1, bool MM = true>
 __device__ __forceinline__ void withdraw2(double& b1, double& c1, double t1, double r1, double& g1, double& n1,
                                           double& b2, double& c2, double t2, double r2, double& g2, double& n2) {
     WithdrawCand w1 = withdraw_arith<T1>(b1, c1, t1, r1);
     WithdrawCand w2 = withdraw_arith<T2>(b2, c2, t2, r2);
-    withdraw_fixup(w1, b1, c1, t1, g1, n1);
-    withdraw_fixup(w2, b2, c2, t2, g2, n2);
+    withdraw_fixup<MM>(w1, b1, c1, t1, g1, n1);
+    withdraw_fixup<MM>(w2, b2, c2, t2, g2, n2);
 }
 
 // _rebalance_portfolio (:274-359): every lane evaluates the arithmetic with the over-weight asset as the seller.
-template <bool STRICT = true, bool TAXED = true>
+template <bool STRICT = true, bool TAXED = true, bool MM = true>
 __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, double& c1, double& b2,
                                           double& c2) {
     const double total = b1 + b2;                                  // :288
@@ -417,12 +425,12 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
         b2 = act ? r2 : b2;
         c2 = act ? rc2 : c2;
     } else {   // path form: the same selections as exec-masked moves (see withdraw)
-        if (dust_s) { asm volatile(""); nbs = 0.0; ncs = 0.0; }
-        if (dust_b) { asm volatile(""); nbb = 0.0; ncb = 0.0; }
+        if (dust_s) { MCR_MASKED_MOVE; nbs = 0.0; ncs = 0.0; }
+        if (dust_b) { MCR_MASKED_MOVE; nbb = 0.0; ncb = 0.0; }
         if (act) {
-            asm volatile("");
-            if (sell1) { asm volatile(""); b1 = nbs; c1 = ncs; b2 = nbb; c2 = ncb; }
-            else { asm volatile(""); b1 = nbb; c1 = ncb; b2 = nbs; c2 = ncs; }
+            MCR_MASKED_MOVE;
+            if (sell1) { MCR_MASKED_MOVE; b1 = nbs; c1 = ncs; b2 = nbb; c2 = ncb; }
+            else { MCR_MASKED_MOVE; b1 = nbb; c1 = ncb; b2 = nbs; c2 = ncs; }
         }
     }
 }
@@ -432,14 +440,14 @@ __device__ __forceinline__ void rebalance(const LaneParams& P, double& b1, doubl
 // back for the others; the buyer is not selected on the way in: the net purchase is added to BOTH assets in place
 // (:324-325 / :352-353 for whichever is the buyer) and the seller's pair is then overwritten under its own mask
 // (:322-323 / :350-351).  10 v_cndmask + 4 masked moves, against 14 + 8 for the select-in / select-out form.
-template <bool TAXED>
+template <bool TAXED, bool MM = true>
 __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, double& c1, double& b2, double& c2) {
     const double total = b1 + b2;                                  // :288
     const double drift1 = b1 - total * P.alloc1;                   // :293-294
     // (A wave in which no lane acts — e.g. the rebalance that closes the yearly tax step, right after the monthly
     //  one — skips the block through the s_cbranch_execz of this branch: no separate ballot is needed.)
     if ((total > kEps) && (fabs(drift1) > kEps)) {                 // :290-296
-        asm volatile("");
+        MCR_MASKED_MOVE;
         const bool sell1 = drift1 > 0.0;                           // :298
         const double drift2 = b2 - total * P.alloc2;               // :328
         const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;   // seller
@@ -469,10 +477,10 @@ __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, 
         //  through a selected pointer, which pins the whole state in scratch memory)
         double r1b = b1 + net_purchase, r1c = c1 + net_purchase;   // :324-325 for the buyer; the seller's pair is replaced below
         double r2b = b2 + net_purchase, r2c = c2 + net_purchase;
-        if (sell1) { asm volatile(""); r1b = nbs; r1c = ncs; }
-        else { asm volatile(""); r2b = nbs; r2c = ncs; }
-        if (r1b <= kEps) { asm volatile(""); r1b = 0.0; r1c = 0.0; }  // :355-358
-        if (r2b <= kEps) { asm volatile(""); r2b = 0.0; r2c = 0.0; }
+        if (sell1) { MCR_MASKED_MOVE; r1b = nbs; r1c = ncs; }
+        else { MCR_MASKED_MOVE; r2b = nbs; r2c = ncs; }
+        if (r1b <= kEps) { MCR_MASKED_MOVE; r1b = 0.0; r1c = 0.0; }  // :355-358
+        if (r2b <= kEps) { MCR_MASKED_MOVE; r2b = 0.0; r2c = 0.0; }
         b1 = r1b; c1 = r1c; b2 = r2b; c2 = r2c;
     }
 }
@@ -480,7 +488,7 @@ __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, 
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
 // ANNUAL = false: compile-time variant for scenarios in which no asset is on the annual-gains system (annual
 // bill identically 0, :380-390): the block below and the monthly gain accumulators are dead code.
-template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true, bool T1 = TAXED, bool T2 = TAXED>
+template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true, bool T1 = TAXED, bool T2 = TAXED, bool MM = true>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
@@ -488,8 +496,8 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         const double due1 = fmax(0.0, gain1) * P.annual_rate1;        // :380-384
         const double due2 = fmax(0.0, gain2) * P.annual_rate2;        // :385-389
         const double total_due = due1 + due2;                         // :390
-        const double cap1 = net_liquidation_value<STRICT, T1>(b1, c1, L.real_rate1);  // :392-397
-        const double cap2 = net_liquidation_value<STRICT, T2>(b2, c2, L.real_rate2);  // :398-403
+        const double cap1 = net_liquidation_value<STRICT, T1, MM>(b1, c1, L.real_rate1);  // :392-397
+        const double cap2 = net_liquidation_value<STRICT, T2, MM>(b2, c2, L.real_rate2);  // :398-403
         const double cap = cap1 + cap2;                               // :404
         const double pay = fmin(total_due, cap);                      // :405
         tax_failed = pay < total_due - kEps;                          // :406
@@ -497,13 +505,13 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
             const double share1 = fdiv<STRICT>(cap1, cap);            // :409
             const double share2 = 1.0 - share1;                       // :410
             double g, net1, net2;
-            withdraw<STRICT, T1>(b1, c1, pay * share1, L.real_rate1, g, net1);  // :411-419
-            withdraw<STRICT, T2>(b2, c2, pay * share2, L.real_rate2, g, net2);  // :420-428
+            withdraw<STRICT, T1, MM>(b1, c1, pay * share1, L.real_rate1, g, net1);  // :411-419
+            withdraw<STRICT, T2, MM>(b2, c2, pay * share2, L.real_rate2, g, net2);  // :420-428
             tax_failed = tax_failed || (net1 + net2 < total_due - kEps);  // :429-430
         }
     }
-    if (STRICT) rebalance<true, TAXED>(L, b1, c1, b2, c2);  // :432-442 (always)
-    else rebalance_path<TAXED>(L, b1, c1, b2, c2);
+    if (STRICT) rebalance<true, TAXED, MM>(L, b1, c1, b2, c2);  // :432-442 (always)
+    else rebalance_path<TAXED, MM>(L, b1, c1, b2, c2);
     return tax_failed;
 }
 

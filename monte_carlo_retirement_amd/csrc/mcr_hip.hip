@@ -95,6 +95,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
+    constexpr bool MM = !SPLIT;          // exec-masked moves (issue-bound launches) vs the compiler's selects (latency-bound SPLIT launches): MCR_MASKED_MOVE, mcr_device.h
     constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
     const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
     const bool producer = SPLIT && threadIdx.x >= (unsigned)kBlock;                  // wave-uniform (kBlock = 4 wavefronts)
@@ -296,9 +297,9 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance_path<TANY>(L, b1, c1, b2, c2);                       // :549-553
+        rebalance_path<TANY, MM>(L, b1, c1, b2, c2);                   // :549-553
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes<false, TANY, ANNUAL, T1, T2>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -372,30 +373,30 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     if (!kStaged) growth(wm + rmi, g1, ginf, g2);      // :692-705 (sequential generators draw here)
                     market_step<ANNUAL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl);  // :706-714
                     if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
-                        asm volatile("");                              // keep it a branch: no lane takes it in most months
+                        MCR_MASKED_MOVE;                              // keep it a branch: no lane takes it in most months
                         b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
                         yfail = true; stop = true;
                     }
                 }
                 if (!stop) {
                     double cap1, cap2;
-                    net_liquidation_values2<T1, T2>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
+                    net_liquidation_values2<T1, T2, MM>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
                     const double cap = cap1 + cap2;                                   // :738
                     const double target = fmin(need, cap);                            // :739-742 (need, cap >= 0: the max(0, .) is a no-op)
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
                     double prop1 = fdiv<false>(cap1, cap);                            // :750-754
-                    if (!(cap > kEps)) { asm volatile(""); prop1 = P.alloc1; }        // (exec-masked move, not a select)
+                    if (!(cap > kEps)) { MCR_MASKED_MOVE; prop1 = P.alloc1; }        // (exec-masked move, not a select)
                     const double prop2 = 1.0 - prop1;                                 // :755
                     double gw1, nw1, gw2, nw2;
-                    withdraw2<T1, T2>(b1, c1, target * prop1, L.real_rate1, gw1, nw1,  // :757-765
+                    withdraw2<T1, T2, MM>(b1, c1, target * prop1, L.real_rate1, gw1, nw1,  // :757-765
                                      b2, c2, target * prop2, L.real_rate2, gw2, nw2);  // :768-776
                     tg1 += gw1;                                                       // :766
                     tg2 += gw2;                                                       // :777
                     if (kSummary) treal += fdiv<false>((gw1 + gw2) * infl_ret, fmax(price, kEps));  // :778-782
                     if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance_path<TANY>(L, b1, c1, b2, c2);                          // :792-796
+                    rebalance_path<TANY, MM>(L, b1, c1, b2, c2);                      // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
-                        const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
                         yfail = yfail || tf;                                          // :821-822
                     }
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
             if (tf) {                                                            // :894-896
                 succeeded = false; ruin_bin = ry + 1;
                 if (kSumLds) sum_col[2 * kBlock] = (double)ry; else ytr_bits = f64_bits((double)ry);
