@@ -95,7 +95,11 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
+#ifdef MCR_K1_FORCE_SELECTS
+    constexpr bool MM = false;           // (A/B builds only)
+#else
     constexpr bool MM = !SPLIT;          // exec-masked moves (issue-bound launches) vs the compiler's selects (latency-bound SPLIT launches): MCR_MASKED_MOVE, mcr_device.h
+#endif
     constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
     const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
     const bool producer = SPLIT && threadIdx.x >= (unsigned)kBlock;                  // wave-uniform (kBlock = 4 wavefronts)
