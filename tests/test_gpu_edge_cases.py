@@ -384,10 +384,19 @@ def test_producer_consumer_split_counts_are_bit_identical(monkeypatch):
     bin, observation count and histogram bin must equal the unsplit launch — also when whole workgroups fail early, for
     odd / even / zero working months, ragged sizes, and through the shared-accumulation probes of the search."""
     rng = np.random.default_rng(int(os.environ.get("MCR_SPLIT_FUZZ_SEED", "20261004")))
-    cfgs = load_golden("paths_injected.json")
+    cfgs = list(load_golden("paths_injected.json"))
+    # the split variants keep the first two income-stream records in SGPRs and read the others every month: a scenario with
+    # five streams of every kind (indexed / frozen, open-ended / limited, starting before and after retirement) covers both
+    many = dict(cfgs[0]["cfg"], other_income_streams=[
+        dict(name="a", monthly_amount_today=1500.0, start_at_age=62.0, duration_years=None, inflation_indexed=True, tax_rate=0.1),
+        dict(name="b", monthly_amount_today=900.0, start_at_age=45.0, duration_years=30, inflation_indexed=False, tax_rate=0.2),
+        dict(name="c", monthly_amount_today=700.0, start_at_age=70.0, duration_years=10, inflation_indexed=True, tax_rate=0.0),
+        dict(name="d", monthly_amount_today=1200.0, start_at_age=66.5, duration_years=None, inflation_indexed=False, tax_rate=0.3),
+        dict(name="e", monthly_amount_today=0.0, start_at_age=40.0, duration_years=50, inflation_indexed=False, tax_rate=0.25)])
+    five = dict(name="FIVE_STREAMS", cfg=many, working_months=cfgs[0]["working_months"])
     edges = np.geomspace(1.0, 1e12, 41)
     for it in range(int(os.environ.get("MCR_SPLIT_FUZZ_ROUNDS", "24"))):
-        g = cfgs[int(rng.integers(len(cfgs)))]
+        g = five if it < 4 else cfgs[int(rng.integers(len(cfgs)))]
         p = params_from_config(Config(**g["cfg"]))
         wm = int(rng.choice([0, 1, 2, 11, 12, 13, g["working_months"], g["working_months"] + 1, int(rng.integers(0, 400))]))
         n = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 50_000, int(rng.integers(1, 150_000))]))
