@@ -24,8 +24,9 @@
 extern "C" {
 #endif
 
-#define MCR_ABI_VERSION 6
-#define MCR_MAX_STREAMS 16      /* other_income_streams entries carried in mcr_params */
+#define MCR_ABI_VERSION 7
+#define MCR_INLINE_STREAMS 16   /* other_income_streams entries carried INSIDE mcr_params; the rest of the list (any length,
+                                   backend/config.py:99) follows through mcr_params.extra_streams */
 #define MCR_MAX_PROBE_CANDIDATES 32 /* candidates of one mcr_probe_months_rng call that can share their accumulation sweep */
 #define MCR_MAX_HIST_BINS 4096  /* bins of the in-kernel final-balance histogram (mcr_outputs.hist_bins) */
 #define MCR_MONTHS_PER_YEAR 12  /* backend/constants.py:1 */
@@ -99,8 +100,13 @@ typedef struct mcr_params {
     int32_t retirement_years;               /* config.py:68 (> 0) */
     int32_t inv1_use_realized_gains_tax_system; /* config.py:75 (0/1) */
     int32_t inv2_use_realized_gains_tax_system; /* config.py:81 (0/1) */
-    int32_t n_streams;                      /* len(other_income_streams) <= MCR_MAX_STREAMS */
-    mcr_stream streams[MCR_MAX_STREAMS];    /* config.py:99, list order preserved */
+    int32_t n_streams;                      /* len(other_income_streams): ANY length >= 0, as in the reference (config.py:99) */
+    mcr_stream streams[MCR_INLINE_STREAMS]; /* config.py:99, list order preserved: entries 0 .. min(n_streams, 16) - 1 */
+    /* Entries MCR_INLINE_STREAMS .. n_streams - 1 of the list, in order (a HOST pointer on every entry point: the
+     * parameter block is always host memory; the library copies the records into a device table next to the launch).
+     * Must be non-NULL when n_streams > MCR_INLINE_STREAMS; ignored otherwise.  The loop over the streams is the
+     * reference's (backend/simulation.py:602-621, 649-677): O(n_streams) per retirement month, whatever the length. */
+    const mcr_stream* extra_streams;
 } mcr_params;
 
 /* Shapes implied by (params, working_months); simulation.py:487,585-589,902. */
@@ -178,12 +184,12 @@ int mcr_release_cached(int device);
 
 /* ---- host-side derivations (no device needed) -------------------------------------- */
 /* Shapes for (params, working_months).  Returns MCR_ERR_INVALID_ARG for working_months<0,
- * retirement_years<=0, n_streams out of range. */
+ * retirement_years<=0, n_streams<0. */
 int mcr_query_sizes(const mcr_params* p, int32_t working_months, mcr_sizes* out);
 /* Range check of a parameter block — what the reference's pydantic Config enforces (backend/config.py:56-99)
  * and the kernel relies on: amounts finite and >= 0, rates / allocation / stream tax rates in [0, 1], rho in
  * [-1, 1], finite log-parameters with sigma >= 0 and |mu|/12 + 40 sigma/sqrt(12) < 700 (domain of the kernel's
- * exp), n_streams in [0, MCR_MAX_STREAMS].  Every compute entry point applies it and returns
+ * exp), n_streams >= 0 (with extra_streams set beyond MCR_INLINE_STREAMS).  Every compute entry point applies it and returns
  * MCR_ERR_INVALID_ARG (message via mcr_last_error) instead of computing with out-of-range inputs.  Not
  * checkable up front: balances are assumed to stay within 1e-6 .. 1e15 (unscaled fp64 division). */
 int mcr_validate_params(const mcr_params* p);

@@ -12,8 +12,8 @@ import os
 import threading
 from typing import Optional
 
-MCR_ABI_VERSION = 6
-MCR_MAX_STREAMS = 16
+MCR_ABI_VERSION = 7
+MCR_INLINE_STREAMS = 16  # other_income_streams records inside mcr_params; the rest follow through extra_streams
 MCR_N_COUNTERS = 2
 MCR_N_STAT_ROWS = 4
 MCR_CTR_SUCCESS = 0
@@ -104,8 +104,33 @@ class McrParams(C.Structure):
         ("inv1_use_realized_gains_tax_system", C.c_int32),
         ("inv2_use_realized_gains_tax_system", C.c_int32),
         ("n_streams", C.c_int32),
-        ("streams", McrStream * MCR_MAX_STREAMS),
+        ("streams", McrStream * MCR_INLINE_STREAMS),
+        ("extra_streams", C.POINTER(McrStream)),
     ]
+
+    #: the ctypes array `extra_streams` points into (a Structure keeps no reference to what its pointer fields point at)
+    _extra_keepalive = None
+
+    def set_streams(self, records) -> None:
+        """Fill the stream list from `(monthly_amount_today, start_at_age, tax_rate, duration_years, inflation_indexed)`
+        tuples — ANY number of them (backend/config.py:99 has no limit): the first MCR_INLINE_STREAMS go into the block, the
+        rest into an array this object keeps alive and `extra_streams` points at."""
+        records = list(records)
+        self.n_streams = len(records)
+        extra = (McrStream * max(0, len(records) - MCR_INLINE_STREAMS))()
+        for i, (amount, start_age, tax_rate, duration_years, indexed) in enumerate(records):
+            s = self.streams[i] if i < MCR_INLINE_STREAMS else extra[i - MCR_INLINE_STREAMS]
+            s.monthly_amount_today = amount
+            s.start_at_age = start_age
+            s.tax_rate = tax_rate
+            s.duration_years = -1 if duration_years is None else int(duration_years)
+            s.inflation_indexed = int(bool(indexed))
+        self._extra_keepalive = extra if len(extra) else None
+        self.extra_streams = C.cast(extra, C.POINTER(McrStream)) if len(extra) else C.POINTER(McrStream)()
+
+    def stream(self, i: int) -> McrStream:
+        """Entry i of the list, wherever it lives."""
+        return self.streams[i] if i < MCR_INLINE_STREAMS else self.extra_streams[i - MCR_INLINE_STREAMS]
 
 
 class McrRng(C.Structure):

@@ -38,8 +38,13 @@ struct DevStream {
     int32_t start_month;  // stream_payment_start_month_index    (:47-63, :603-608)
     int32_t end_month;    // start + duration_years*12, INT32_MAX for None (:609-613, :653-656)
     int32_t indexed;      // inflation_indexed
-    int32_t lock_slot;    // LDS column of the frozen nominal amount (non-indexed streams), else -1
+    int32_t lock_slot;    // column of the frozen nominal amount (non-indexed streams), else -1: slots below
+                          // DevParams::n_lock_slots are LDS columns, the others rows of DevParams::lock_overflow
 };
+// Records past the by-value block live in a device table that the kernel reads through the CONSTANT address space:
+// scalar loads (s_load_dwordx8, the record lands in SGPRs like a kernel argument) whatever the alias analysis makes of the
+// kernel's own stores.
+typedef const __attribute__((address_space(4))) DevStream* DevStreamTable;
 
 // Wave-uniform scenario block (kernel argument -> SGPRs).
 struct DevParams {
@@ -53,12 +58,20 @@ struct DevParams {
     double rho, rho_c;                 // rho, sqrt(max(0, 1 - rho^2))               (:460-464)
     double binf_rho, binf_rho_c;       // binf * rho, binf * rho_c: the inflation log-return straight from two normals (growth_rows2)
     int32_t working_months, retirement_years, total_months, shock_rows;
-    int32_t num_working_years, trajectory_len, n_streams, n_lock_slots;
+    int32_t num_working_years, trajectory_len;
+    int32_t n_streams;                 // records in `streams` below: min(len(other_income_streams), MCR_INLINE_STREAMS)
+    int32_t n_lock_slots;              // lock slots kept in LDS ([n_lock_slots][kBlock] doubles); the launcher decides (LDS budget)
     int32_t contrib_grows;             // contribution_growth_rate_annual > 0        (:516)
     int32_t any_annual_tax;            // annual_rate1 > 0 || annual_rate2 > 0
     int32_t any_real_rate;             // real_rate1 > 0 || real_rate2 > 0
     int32_t tax_mask;                  // bit 0: real_rate1 > 0, bit 1: real_rate2 > 0  -> selects the TAXED kernel variant (0 .. 3)
-    DevStream streams[MCR_MAX_STREAMS];
+    DevStream streams[MCR_INLINE_STREAMS];
+    // other_income_streams beyond the by-value block (the list has any length, config.py:99)
+    int32_t n_extra_streams;           // records in `extra_streams`
+    int32_t n_lock_slots_total;        // non-indexed streams of the whole list (derive_params numbers their slots in list order)
+    const DevStream* extra_streams;    // DEVICE table [n_extra_streams] (read through DevStreamTable), nullptr if none
+    double* lock_overflow;             // DEVICE [n_lock_slots_total - n_lock_slots][lock_stride]: the slots that did not fit in LDS
+    int64_t lock_stride;               // = grid.x * kBlock: every lane of the launch has its own column
 };
 
 // The four parameters that feed per-lane SELECTS (seller's weight / seller's rate).  They are

@@ -88,10 +88,16 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // halves of a month's dependency chain then run on different SIMDs of the CU.  One workgroup barrier per pair of months
 // hands a buffer over; every wave executes the same number of them (no early exit when all lanes have failed) or has
 // terminated.  The arithmetic of every path is unchanged: counts are bit-identical to SPLIT = false.
-template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false>
+// XS = true ("extended streams"): the variants that can read income-stream records beyond the by-value block from the device
+// table and keep lock slots beyond the LDS budget in the global overflow block (DevParams::extra_streams / lock_overflow:
+// other_income_streams has no length limit in the reference, config.py:99).  A compile-time variant because the headline
+// kernels have no SGPR to spare for the two extra tests a month; instantiated for the generic tax form only (TAXED = 3,
+// ANNUAL = true: exact zeros for a zero rate, like the NumPy-stream variants).
+template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false, bool XS = false>
 __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
+    static_assert(!XS || (PHASE == 0 && !SPLIT && TAXED == 3 && ANNUAL), "extended stream lists run the generic whole-path form");
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
@@ -354,10 +360,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     double nominal;
                     if (S.indexed) {
                         nominal = S.amount * price;                    // :661-665
-                    } else {
+                    } else if (!XS || S.lock_slot < P.n_lock_slots) {      // (wave-uniform; without XS every slot is an LDS column)
                         double* slot = lock_lds + (size_t)S.lock_slot * kBlock + tid;
                         if (rmi == S.start_month) *slot = S.amount * price;  // :667-671 (first active month)
                         nominal = *slot;                               // :672-674
+                    } else {                                           // a slot beyond the LDS budget: the lane's column of the overflow block
+                        double* slot = P.lock_overflow + (size_t)(S.lock_slot - P.n_lock_slots) * (size_t)P.lock_stride + (size_t)local;
+                        if (rmi == S.start_month) *slot = S.amount * price;
+                        nominal = *slot;
                     }
                     income += nominal * S.keep;                        // :675-677
                 };
@@ -368,6 +378,15 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     s = 2;
                 }
                 for (; s < P.n_streams; ++s) stream_income(P.streams[s]);    // :650 (wave-uniform; the record is re-read from the kernel arguments)
+                if (XS && P.n_extra_streams > 0) {                                 // the rest of the list (config.py:99 has no length limit): scalar loads from the device table
+                    const DevStreamTable xs = (DevStreamTable)P.extra_streams;
+                    for (int x = 0; x < P.n_extra_streams; ++x) {
+                        DevStream S;
+                        S.amount = xs[x].amount; S.keep = xs[x].keep; S.start_month = xs[x].start_month;
+                        S.end_month = xs[x].end_month; S.indexed = xs[x].indexed; S.lock_slot = xs[x].lock_slot;
+                        stream_income(S);
+                    }
+                }
                 const double need = fmax(0.0, expenses - income);      // :679-682
                 bool stop = false;
                 if (b1 + b2 <= kEps && need > kEps) {                  // :684-690 (FAIL-1, no shock consumed)
@@ -807,6 +826,20 @@ void stream_fork_release(StreamFork* f) {
 // weights in [0, 1] and non-negative amounts; fexp needs |x| < 700).  The reference enforces the same ranges
 // in its pydantic Config (backend/config.py:56-99); a ctypes caller that bypasses Config gets an error here,
 // not silently different arithmetic.
+// other_income_streams has any length (backend/config.py:99): the first MCR_INLINE_STREAMS records sit in the block, the
+// rest behind mcr_params.extra_streams (a host pointer)
+static inline const mcr_stream& stream_at(const mcr_params* p, int s) {
+    return s < MCR_INLINE_STREAMS ? p->streams[s] : p->extra_streams[s - MCR_INLINE_STREAMS];
+}
+static int check_stream_list(const mcr_params* p) {
+    if (p->n_streams < 0) { set_error("n_streams %d must be >= 0", p->n_streams); return MCR_ERR_INVALID_ARG; }
+    if (p->n_streams > MCR_INLINE_STREAMS && !p->extra_streams) {
+        set_error("n_streams = %d but extra_streams is NULL (entries %d.. of the list go there)", p->n_streams, MCR_INLINE_STREAMS);
+        return MCR_ERR_INVALID_ARG;
+    }
+    return MCR_OK;
+}
+
 static int validate_params(const mcr_params* p) {
     if (!p) { set_error("null params"); return MCR_ERR_INVALID_ARG; }
     auto bad = [](const char* name, double v, const char* want) {
@@ -838,9 +871,9 @@ static int validate_params(const mcr_params* p) {
             return MCR_ERR_INVALID_ARG;
         }
     }
-    if (p->n_streams < 0 || p->n_streams > MCR_MAX_STREAMS) { set_error("n_streams %d out of range [0, %d]", p->n_streams, MCR_MAX_STREAMS); return MCR_ERR_INVALID_ARG; }
+    if (int rc = check_stream_list(p)) return rc;
     for (int s = 0; s < p->n_streams; ++s) {
-        const mcr_stream& st = p->streams[s];
+        const mcr_stream& st = stream_at(p, s);
         if (!nonneg(st.monthly_amount_today) || !unit(st.tax_rate) || !std::isfinite(st.start_at_age)) {
             set_error("params.streams[%d]: monthly_amount_today %g must be finite and >= 0, tax_rate %g in [0, 1], start_at_age %g finite "
                       "(config.py:18,23,45)", s, st.monthly_amount_today, st.tax_rate, st.start_at_age);
@@ -854,10 +887,7 @@ static int query_sizes(const mcr_params* p, int32_t wm, mcr_sizes* s) {
     if (!p || !s) { set_error("null argument"); return MCR_ERR_INVALID_ARG; }
     if (wm < 0) { set_error("working_months must be >= 0 (got %d)", wm); return MCR_ERR_INVALID_ARG; }
     if (p->retirement_years <= 0) { set_error("retirement_years must be > 0"); return MCR_ERR_INVALID_ARG; }
-    if (p->n_streams < 0 || p->n_streams > MCR_MAX_STREAMS) {
-        set_error("n_streams %d out of range [0, %d]", p->n_streams, MCR_MAX_STREAMS);
-        return MCR_ERR_INVALID_ARG;
-    }
+    if (int rc = check_stream_list(p)) return rc;
     if ((int64_t)wm + (int64_t)p->retirement_years * kMPY > (int64_t)INT32_MAX / 4) {
         set_error("horizon too long");
         return MCR_ERR_INVALID_ARG;
@@ -882,7 +912,9 @@ static int32_t start_month_index(double current_age, int32_t wm, double start_at
 }
 
 // Host-side derivation of the wave-uniform parameter block (same fp64 expressions as the reference).
-static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
+// `extra` receives the records of the streams beyond the by-value block (device-table layout); callers that cannot carry
+// such a table pass nullptr and get MCR_ERR_UNSUPPORTED for longer lists.
+static int derive_params(const mcr_params* p, int32_t wm, DevParams* d, std::vector<DevStream>* extra = nullptr) {
     mcr_sizes sz;
     int rc = query_sizes(p, wm, &sz);
     if (rc != MCR_OK) return rc;
@@ -923,11 +955,14 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
     d->shock_rows = sz.shock_rows;
     d->num_working_years = sz.num_working_years;
     d->trajectory_len = sz.trajectory_len;
-    d->n_streams = p->n_streams;
+    d->n_streams = p->n_streams < MCR_INLINE_STREAMS ? p->n_streams : MCR_INLINE_STREAMS;
+    d->n_extra_streams = p->n_streams - d->n_streams;
+    if (extra) extra->assign((size_t)d->n_extra_streams, DevStream{});
     int slots = 0;
     for (int s = 0; s < p->n_streams; ++s) {
-        const mcr_stream& in = p->streams[s];
-        DevStream& o = d->streams[s];
+        const mcr_stream& in = stream_at(p, s);
+        DevStream scratch;
+        DevStream& o = s < MCR_INLINE_STREAMS ? d->streams[s] : (extra ? (*extra)[(size_t)(s - MCR_INLINE_STREAMS)] : scratch);
         o.amount = in.monthly_amount_today;
         o.keep = 1.0 - in.tax_rate;  // :676
         o.start_month = start_month_index(p->current_age, wm, in.start_at_age);  // :603-608
@@ -940,11 +975,75 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d) {
         o.indexed = in.inflation_indexed ? 1 : 0;
         o.lock_slot = o.indexed ? -1 : slots++;
     }
-    d->n_lock_slots = slots;
+    d->n_lock_slots_total = slots;
+    d->n_lock_slots = slots;     // (the launcher lowers it to what its kernel variant's LDS budget holds: plan_lock_slots)
     return MCR_OK;
 }
 
-constexpr size_t kPathKernelStaticLds = (size_t)kMathTabBytes + (size_t)(2 * kStageDoubles + 3 * kBlock) * sizeof(double);   // (upper bound over the variants)
+// LDS of one path_kernel launch.  STATIC part of the variant — it mirrors the __shared__ declarations at the top of the
+// kernel: the math tables, the stage of growth factors (Philox stream without injection; twice for the producer / consumer
+// form) and the three per-path summary columns (those variants with per-path outputs) — plus the launch's DYNAMIC part: the
+// ziggurat tables (NumPy stream), the block counters / year bins / histogram bins, and as many [kBlock] lock columns of
+// non-indexed income streams as keep FOUR workgroups resident on a CU (160 KB of LDS: 40 KB each), never more than the 64 KB
+// a workgroup may use without opting in; the remaining slots go to a global overflow block (DevParams::lock_overflow).
+// Measured at 10^6 config.json paths (tools/streams_timing.py, profiles/r04): 16 frozen streams with every column in LDS
+// (2 resident workgroups) 18.4 ms count-only, all in the overflow block 12.5 ms; 8 frozen streams (4 resident workgroups
+// with all columns in LDS) 8.7 vs 8.9 ms.  MCR_K1_LDS_LOCK_SLOTS=n in the environment overrides the occupancy rule: up to n
+// slots in LDS (A/B, tests).
+constexpr size_t kLdsPerWorkgroup = 64 * 1024;
+constexpr size_t kLdsForFourResident = 40 * 1024;
+static size_t path_kernel_static_lds(int mode, bool numpy_rng, bool injected, bool split) {
+    const bool staged = !numpy_rng && !injected;
+    return (size_t)kMathTabBytes + (staged ? (size_t)(split ? 2 : 1) * kStageDoubles * sizeof(double) : 16) +
+           ((mode >= 1 && staged) ? (size_t)3 * kBlock * sizeof(double) : 16);
+}
+static int plan_path_kernel_lds(DevParams& d, int mode, bool numpy_rng, bool injected, bool split, int n_hist_bins, size_t* dynamic_bytes) {
+    const size_t fixed = path_kernel_static_lds(mode, numpy_rng, injected, split) + (numpy_rng ? (size_t)kZigLdsBytes : (size_t)0) +
+                         (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1) + n_hist_bins) * sizeof(unsigned int);
+    if (fixed > kLdsPerWorkgroup) { set_error("too many retirement years / histogram bins for the LDS of a workgroup"); return MCR_ERR_UNSUPPORTED; }
+    constexpr size_t kSlotBytes = (size_t)kBlock * sizeof(double);
+    long slots = (long)((kLdsPerWorkgroup - fixed) / kSlotBytes);
+    const char* e = std::getenv("MCR_K1_LDS_LOCK_SLOTS");
+    if (e && *e) slots = std::min(slots, std::max(0l, std::strtol(e, nullptr, 10)));
+    else slots = std::min(slots, fixed < kLdsForFourResident ? (long)((kLdsForFourResident - fixed) / kSlotBytes) : 0l);
+    d.n_lock_slots = (int32_t)std::min<long>(slots, d.n_lock_slots_total);
+    *dynamic_bytes = fixed - path_kernel_static_lds(mode, numpy_rng, injected, split) + (size_t)d.n_lock_slots * kBlock * sizeof(double);
+    return MCR_OK;
+}
+
+// The device side of a launch's stream list: the table of the records beyond the by-value block and the overflow block of
+// lock slots, ONE stream-ordered allocation (freed behind the kernel).  The host copy of the table is owned by the stream
+// until the upload has run (hipLaunchHostFunc): nothing here waits for the device.
+struct StreamSideBlock {
+    void* mem = nullptr;
+    int attach(DevParams& d, const std::vector<DevStream>& extra, unsigned grid_x, hipStream_t stream) {
+        const int n_over = d.n_lock_slots_total - d.n_lock_slots;
+        if (extra.empty() && n_over <= 0) return MCR_OK;
+        d.lock_stride = (int64_t)grid_x * kBlock;
+        const size_t table_bytes = (extra.size() * sizeof(DevStream) + 255) & ~(size_t)255;
+        const size_t over_bytes = (size_t)(n_over > 0 ? n_over : 0) * (size_t)d.lock_stride * sizeof(double);
+        hipError_t e = hipMallocAsync(&mem, table_bytes + over_bytes, stream);
+        if (e != hipSuccess) { mem = nullptr; return hip_fail(e, "income-stream table / lock-slot overflow allocation"); }
+        if (!extra.empty()) {
+            void* host = std::malloc(extra.size() * sizeof(DevStream));
+            if (!host) { set_error("out of host memory"); return MCR_ERR_HIP; }
+            std::memcpy(host, extra.data(), extra.size() * sizeof(DevStream));
+            e = hipMemcpyAsync(mem, host, extra.size() * sizeof(DevStream), hipMemcpyHostToDevice, stream);
+            const hipError_t ef = hipLaunchHostFunc(stream, [](void* h) { std::free(h); }, host);
+            if (ef != hipSuccess) { (void)hipStreamSynchronize(stream); std::free(host); }
+            if (e != hipSuccess) return hip_fail(e, "income-stream table upload");
+            d.extra_streams = (const DevStream*)mem;
+        }
+        if (n_over > 0) d.lock_overflow = (double*)((char*)mem + table_bytes);
+        return MCR_OK;
+    }
+    hipError_t release(hipStream_t stream) {
+        if (!mem) return hipSuccess;
+        const hipError_t e = hipFreeAsync(mem, stream);
+        mem = nullptr;
+        return e;
+    }
+};
 
 // Launches of at most this many path-wavefronts take the producer / consumer split (SPLIT = true): up to 3 per SIMD a
 // wavefront is latency-bound and the second wave per path hides half of its chain; above it the chip is busy either way
@@ -953,13 +1052,6 @@ static unsigned split_max_waves() {   // (read at every launch: tests compare bo
     const char* e = std::getenv("MCR_K1_SPLIT_MAX_WAVES");
     return (e && *e) ? (unsigned)std::strtoul(e, nullptr, 10) : 3072u;
 }
-static size_t path_kernel_lds_bytes(const DevParams& d, bool numpy_rng, int n_hist_bins = 0) {
-    // the dynamic part only: the math tables and the stage of growth factors are static LDS of the kernel
-    return (numpy_rng ? (size_t)kZigLdsBytes : (size_t)0) +
-           (size_t)d.n_lock_slots * kBlock * sizeof(double) +
-           (size_t)(1 + (d.retirement_years + 2) + (d.retirement_years + 1) + n_hist_bins) * sizeof(unsigned int);
-}
-
 static int check_rng(const mcr_rng* rng) {
     if (!rng) { set_error("null rng"); return MCR_ERR_INVALID_ARG; }
     if (rng->kind != MCR_RNG_PHILOX && rng->kind != MCR_RNG_NUMPY) { set_error("unknown rng kind %u", rng->kind); return MCR_ERR_INVALID_ARG; }
@@ -983,7 +1075,8 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
                         uint64_t n_paths, int32_t wm, const double* injected, const mcr_outputs* out,
                         hipStream_t stream) {
     DevParams d;
-    int rc = derive_params(p, wm, &d);
+    std::vector<DevStream> extra;
+    int rc = derive_params(p, wm, &d, &extra);
     if (rc != MCR_OK) return rc;
     rc = check_rng(rng);
     if (rc != MCR_OK) return rc;
@@ -1011,13 +1104,37 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
         set_error("hist_bins requested with hist_n_bins = %d (1..%d) / hist_edges = %p", io.out.hist_n_bins, MCR_MAX_HIST_BINS, (const void*)io.out.hist_edges);
         return MCR_ERR_INVALID_ARG;
     }
-    const size_t lds = path_kernel_lds_bytes(d, np_rng, io.out.hist_n_bins);
-    if (lds + kPathKernelStaticLds > 64 * 1024) { set_error("too many non-indexed streams / retirement years / histogram bins for LDS"); return MCR_ERR_UNSUPPORTED; }
     const dim3 grid((unsigned)((n_paths + kBlock - 1) / kBlock)), block(kBlock);
-    const int mode = want_traj ? 2 : (want_summary ? 1 : 0);
+    const int mode = injected ? 2 : (want_traj ? 2 : (want_summary ? 1 : 0));
     // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
     // shocks (parity hook) always take the full-output variant, whose every store is null-checked
-    const bool split = !injected && !np_rng && mode == 0 && (uint64_t)grid.x * (kBlock / 64) <= split_max_waves();
+    bool split = !injected && !np_rng && mode == 0 && (uint64_t)grid.x * (kBlock / 64) <= split_max_waves();
+    size_t lds = 0;
+    rc = plan_path_kernel_lds(d, mode, np_rng, injected != nullptr, split, io.out.hist_n_bins, &lds);
+    if (rc != MCR_OK) return rc;
+    if (split && (d.n_lock_slots < d.n_lock_slots_total || d.n_extra_streams > 0)) {
+        // the producer / consumer form doubles the stage: where only IT cannot hold every lock column, the unsplit kernel runs
+        split = false;
+        rc = plan_path_kernel_lds(d, mode, np_rng, false, false, io.out.hist_n_bins, &lds);
+        if (rc != MCR_OK) return rc;
+    }
+    // XS: records beyond the by-value block and / or lock slots beyond the LDS budget -> the extended-stream variants
+    const bool xs = d.n_lock_slots < d.n_lock_slots_total || d.n_extra_streams > 0;
+    StreamSideBlock side;
+    rc = side.attach(d, extra, grid.x, stream);
+    if (rc != MCR_OK) { (void)side.release(stream); return rc; }
+    if (xs) {
+#define MCR_LAUNCH_X(M, R, I) hipLaunchKernelGGL((path_kernel<M, R, 3, true, I, 0, false, true>), grid, block, lds, stream, d, io, (const DevParams*)nullptr)
+        if (injected) MCR_LAUNCH_X(2, 0, true);
+        else if (!np_rng) { if (mode == 2) MCR_LAUNCH_X(2, 0, false); else if (mode == 1) MCR_LAUNCH_X(1, 0, false); else MCR_LAUNCH_X(0, 0, false); }
+        else { if (mode == 2) MCR_LAUNCH_X(2, 1, false); else if (mode == 1) MCR_LAUNCH_X(1, 1, false); else MCR_LAUNCH_X(0, 1, false); }
+#undef MCR_LAUNCH_X
+        hipError_t ex = hipGetLastError();
+        const hipError_t ef = side.release(stream);
+        if (ex != hipSuccess) return hip_fail(ex, "path_kernel launch (extended streams)");
+        if (ef != hipSuccess) return hip_fail(ef, "path_kernel launch (extended streams): side block release");
+        return MCR_OK;
+    }
     if (split) {
         const dim3 block2(2 * kBlock);
 #define MCR_LAUNCH_S(T, A) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 0, true>), grid, block2, lds, stream, d, io, (const DevParams*)nullptr)
@@ -1123,9 +1240,13 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
         const int rc = derive_params(p, working_months[order[i]], &blocks[(size_t)i]);
         if (rc != MCR_OK) return rc;
     }
-    const DevParams& top = blocks[(size_t)n_cand - 1];
-    const size_t lds = path_kernel_lds_bytes(top, false);
-    if (lds + kPathKernelStaticLds > 64 * 1024) return MCR_ERR_UNSUPPORTED;
+    DevParams& top = blocks[(size_t)n_cand - 1];
+    // (stream lists beyond the by-value block, or lock slots beyond the LDS of the split form, take one launch per candidate:
+    //  each then carries its own device table / overflow block)
+    if (top.n_extra_streams > 0) return MCR_ERR_UNSUPPORTED;
+    size_t lds = 0;
+    if (plan_path_kernel_lds(top, 0, false, false, true, 0, &lds) != MCR_OK || top.n_lock_slots < top.n_lock_slots_total) return MCR_ERR_UNSUPPORTED;
+    for (DevParams& b : blocks) b.n_lock_slots = top.n_lock_slots;
     KernelIO io;
     std::memset(&io, 0, sizeof(io));
     fill_io_rng(io, rng, nullptr);

@@ -10,7 +10,7 @@ from __future__ import annotations
 import math
 from typing import Tuple
 
-from ._native import MCR_MAX_STREAMS, McrParams
+from ._native import McrParams
 from .config import Config
 
 
@@ -34,11 +34,6 @@ def arithmetic_to_log_params(mean: float, vol: float) -> Tuple[float, float]:
 
 def params_from_config(cfg: Config) -> McrParams:
     """Fill the ``mcr_params`` block (raw Config scalars + derived log parameters)."""
-    if len(cfg.other_income_streams) > MCR_MAX_STREAMS:
-        raise ValueError(
-            f"the HIP engine carries at most {MCR_MAX_STREAMS} other_income_streams "
-            f"(got {len(cfg.other_income_streams)})"
-        )
     p = McrParams()
     p.initial_balance = cfg.initial_balance
     p.monthly_contribution = cfg.monthly_contribution
@@ -63,11 +58,9 @@ def params_from_config(cfg: Config) -> McrParams:
     p.retirement_years = cfg.retirement_years
     p.inv1_use_realized_gains_tax_system = int(cfg.inv1_use_realized_gains_tax_system)
     p.inv2_use_realized_gains_tax_system = int(cfg.inv2_use_realized_gains_tax_system)
-    p.n_streams = len(cfg.other_income_streams)
-    for i, s in enumerate(cfg.other_income_streams):
-        p.streams[i].monthly_amount_today = s.monthly_amount_today
-        p.streams[i].start_at_age = s.start_at_age
-        p.streams[i].tax_rate = s.tax_rate
-        p.streams[i].duration_years = -1 if s.duration_years is None else int(s.duration_years)
-        p.streams[i].inflation_indexed = int(s.inflation_indexed)
+    # other_income_streams: any length, list order preserved (config.py:99; simulation.py:602-621 loops over all of them)
+    p.set_streams(
+        (s.monthly_amount_today, s.start_at_age, s.tax_rate, s.duration_years, s.inflation_indexed)
+        for s in cfg.other_income_streams
+    )
     return p

@@ -264,7 +264,7 @@ void orc_draw_shocks(uint64_t seed, uint32_t stream_id, uint64_t path, int32_t n
 /* ------------------------------------------------------------------------------------ */
 int orc_query_sizes(const mcr_params* p, int32_t wm, mcr_sizes* s) {
     if (!p || !s || wm < 0 || p->retirement_years <= 0 || p->n_streams < 0 ||
-        p->n_streams > MCR_MAX_STREAMS)
+        (p->n_streams > MCR_INLINE_STREAMS && !p->extra_streams))
         return MCR_ERR_INVALID_ARG;
     s->total_months = wm + p->retirement_years * MPY;                   /* :487 */
     s->shock_rows = s->total_months > 1 ? s->total_months : 1;          /* :488 */
@@ -273,6 +273,11 @@ int orc_query_sizes(const mcr_params* p, int32_t wm, mcr_sizes* s) {
     s->retirement_years = p->retirement_years;
     s->ruin_bins = p->retirement_years + 2;
     return MCR_OK;
+}
+
+/* entry s of other_income_streams: the first MCR_INLINE_STREAMS records sit in the block, the rest behind extra_streams */
+static inline const mcr_stream* orc_stream(const mcr_params* p, int32_t s) {
+    return s < MCR_INLINE_STREAMS ? &p->streams[s] : &p->extra_streams[s - MCR_INLINE_STREAMS];
 }
 
 typedef struct orc_path_result {
@@ -346,12 +351,14 @@ static void orc_single_path(const mcr_params* p, int32_t working_months, const d
         traj[n_traj] = start_balance; px[n_traj] = infl_ret; n_traj++;
     }
     /* :602-621 per-stream start month / duration; nominal_fixed "None" tracked by a flag */
-    int32_t s_start[MCR_MAX_STREAMS], s_dur[MCR_MAX_STREAMS];
-    int s_fixed_set[MCR_MAX_STREAMS];
-    double s_fixed[MCR_MAX_STREAMS];
+    const size_t ns = (size_t)(p->n_streams > 0 ? p->n_streams : 1);   /* the list has any length (config.py:99) */
+    int32_t* s_start = (int32_t*)malloc(sizeof(int32_t) * ns);
+    int32_t* s_dur = (int32_t*)malloc(sizeof(int32_t) * ns);
+    int* s_fixed_set = (int*)malloc(sizeof(int) * ns);
+    double* s_fixed = (double*)malloc(sizeof(double) * ns);
     for (int32_t s = 0; s < p->n_streams; ++s) {
-        s_start[s] = orc_stream_start_month_index(p->current_age, working_months, p->streams[s].start_at_age);
-        s_dur[s] = p->streams[s].duration_years < 0 ? -1 : p->streams[s].duration_years * MPY;
+        s_start[s] = orc_stream_start_month_index(p->current_age, working_months, orc_stream(p, s)->start_at_age);
+        s_dur[s] = orc_stream(p, s)->duration_years < 0 ? -1 : orc_stream(p, s)->duration_years * MPY;
         s_fixed_set[s] = 0; s_fixed[s] = 0.0;
     }
     double fy_gross = 0.0, fy_real = 0.0; /* :623-624 */
@@ -371,14 +378,15 @@ static void orc_single_path(const mcr_params* p, int32_t working_months, const d
             for (int32_t s = 0; s < p->n_streams; ++s) {    /* :650 */
                 int active = rmi >= s_start[s] && (s_dur[s] < 0 || rmi < s_start[s] + s_dur[s]); /* :653-656 */
                 if (!active) continue;
+                const mcr_stream* st = orc_stream(p, s);
                 double nominal;
-                if (p->streams[s].inflation_indexed) {
-                    nominal = p->streams[s].monthly_amount_today * price; /* :661-665 */
+                if (st->inflation_indexed) {
+                    nominal = st->monthly_amount_today * price; /* :661-665 */
                 } else {
-                    if (!s_fixed_set[s]) { s_fixed[s] = p->streams[s].monthly_amount_today * price; s_fixed_set[s] = 1; } /* :667-671 */
+                    if (!s_fixed_set[s]) { s_fixed[s] = st->monthly_amount_today * price; s_fixed_set[s] = 1; } /* :667-671 */
                     nominal = s_fixed[s];
                 }
-                income += nominal * (1.0 - p->streams[s].tax_rate); /* :675-677 */
+                income += nominal * (1.0 - st->tax_rate); /* :675-677 */
             }
             double need = pymax(0.0, expenses - income); /* :679-682 */
             double tot_before = bal1 + bal2;             /* :684 */
@@ -469,6 +477,7 @@ static void orc_single_path(const mcr_params* p, int32_t working_months, const d
     res->inflation_at_retirement = infl_ret;     /* :949 */
     res->ruin_bin = ruin_bin;
     free(traj); free(px); free(wr);
+    free(s_start); free(s_dur); free(s_fixed_set); free(s_fixed);
 }
 
 /*

@@ -401,6 +401,55 @@ def gen_fuzz():
     nfail = sum(1 for g in groups for p in g["results"] if not p["Success"])
     pre = sum(1 for g in groups for p in g["results"] if p["YearsToRuin"] == 0.0)
     print(f"  fuzz: {len(groups)} scenarios, {nfail} failing paths, {pre} pre-retirement tax failures", flush=True)
+    return groups + gen_many_streams()
+
+
+def gen_many_streams():
+    """Scenarios with MORE other_income_streams than the engine's by-value block holds (16): the reference takes any list
+    (backend/config.py:99; loops backend/simulation.py:602-621, 649-677).  Indexed / frozen, finite / endless / zero-length,
+    overlapping windows, starts before / at / after retirement.  Appended to paths_fuzz.json behind the 48 random
+    scenarios (own generator state: those stay bit-identical)."""
+    rng = np.random.default_rng(20261005)
+
+    def streams(n, frozen_share, cur_age, horizon):
+        out = []
+        for s in range(n):
+            indexed = bool(rng.random() >= frozen_share)
+            dur = None if rng.random() < 0.3 else int(rng.integers(0, max(2, horizon // 2)))
+            out.append(pension(float(rng.uniform(20.0, 600.0)), float(cur_age + rng.uniform(-3.0, horizon * 0.8)),
+                               indexed=indexed, tax=float(rng.choice([0.0, 0.15, rng.uniform(0, 0.45)])), dur=dur, name=f"s{s}"))
+        return out
+
+    c3 = load_json("jorge.json")
+    table = [
+        # name, base cfg, n_streams, share of non-indexed, working months, stream, seed, paths
+        ("streams17_boundary", dict(c3, equity_inflation_correlation=0.3), 17, 0.5, 75, "final", 4711, 6),
+        ("streams20_mixed", base_test_config(
+            initial_balance=650_000.0, monthly_contribution=800.0, monthly_expenses=4_600.0, current_age=52.0,
+            retirement_years=30, inv1_returns_volatility=0.18, inv1_use_realized_gains_tax_system=True,
+            inv1_realized_gains_tax_rate=0.15, inv2_use_realized_gains_tax_system=True, inv2_realized_gains_tax_rate=0.2,
+            inflation_rate_volatility=0.02, equity_inflation_correlation=-0.2), 20, 0.5, 30, "search", 20, 12),
+        ("streams33_all_frozen", base_test_config(
+            initial_balance=520_000.0, monthly_expenses=4_000.0, current_age=60.0, retirement_years=25,
+            inv1_returns_volatility=0.2, inflation_rate_mean=0.05, inflation_rate_volatility=0.03), 33, 1.0, 0, "final", 33, 8),
+        ("streams40_mixed_annual_tax", base_test_config(
+            initial_balance=600_000.0, monthly_contribution=1_500.0, contribution_growth_rate_annual=0.03,
+            monthly_expenses=7_500.0, current_age=45.5, retirement_years=35, allocation_inv1_pct=0.7,
+            inv1_returns_mean=0.09, inv1_returns_volatility=0.17, inv1_use_realized_gains_tax_system=False,
+            inv1_annual_tax_on_gains_rate=0.15, inv2_use_realized_gains_tax_system=True, inv2_realized_gains_tax_rate=0.15,
+            inflation_rate_mean=0.035, inflation_rate_volatility=0.015, equity_inflation_correlation=0.4), 40, 0.7, 49, "final", 40, 12),
+    ]
+    groups = []
+    for name, cfgd, n_streams, frozen_share, wm, stream, seed, n in table:
+        cfgd = dict(cfgd, other_income_streams=streams(n_streams, frozen_share, cfgd["current_age"], cfgd["retirement_years"]))
+        sim = make_sim(cfgd, seed=seed)
+        getattr(sim, f"use_{stream}_seeds")()
+        inject_engine_shocks(sim, seed)
+        paths = [result_to_jsonable(sim._run_single_simulation_path(wm, i)) for i in range(n)]
+        groups.append({"name": name, "cfg": cfgd, "working_months": wm, "stream": stream,
+                       "seed": seed, "path_begin": 0, "n_paths": n, "results": paths})
+        print(f"  {name}: {n_streams} streams ({sum(not s['inflation_indexed'] for s in cfgd['other_income_streams'])} frozen), "
+              f"success={sum(p['Success'] for p in paths)}/{n}", flush=True)
     return groups
 
 

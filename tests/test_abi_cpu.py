@@ -37,7 +37,7 @@ def test_header_and_binding_agree_on_symbols(lib):
 
 def test_struct_layout_matches_header():
     assert C.sizeof(N.McrStream) == 32
-    assert C.sizeof(N.McrParams) == 17 * 8 + 4 * 4 + N.MCR_MAX_STREAMS * 32
+    assert C.sizeof(N.McrParams) == 17 * 8 + 4 * 4 + N.MCR_INLINE_STREAMS * 32 + 8
     assert C.sizeof(N.McrSizes) == 24
     assert C.sizeof(N.McrOutputs) == 17 * 8
 
@@ -88,7 +88,8 @@ def test_validate_params_rejects_what_the_config_would(lib):
                          ("initial_balance", -1.0), ("monthly_expenses", float("inf")), ("monthly_contribution", -5.0),
                          ("contribution_growth_rate_annual", -0.01), ("equity_inflation_rho", 1.2),
                          ("inv1_sigma_log", -0.1), ("inf_mu_log", float("nan")), ("prem_sigma_log", 100.0),
-                         ("n_streams", N.MCR_MAX_STREAMS + 1), ("n_streams", -1)]:
+                         ("n_streams", N.MCR_INLINE_STREAMS + 1),   # (beyond the block with extra_streams == NULL)
+                         ("n_streams", -1)]:
         bad = params_from_config(cfg)
         setattr(bad, field, value)
         assert lib.mcr_validate_params(C.byref(bad)) == -1, field
@@ -104,6 +105,26 @@ def test_validate_params_rejects_what_the_config_would(lib):
     o = N.McrOutputs()
     assert lib.mcr_run_batch_host(C.byref(bad), 1, 1, 0, 8, 12, None, C.byref(o), 0) != 0
     assert lib.mcr_validate_params(None) == -1
+
+
+def test_stream_lists_of_any_length_are_valid(lib):
+    """other_income_streams has no length limit in the reference (backend/config.py:99): 16 records sit in the block, the
+    rest behind `extra_streams`; the host-side checks walk the whole list."""
+    cfgd = dict(load_golden("paths_fuzz.json")[-1]["cfg"])          # streams40_mixed_annual_tax
+    assert len(cfgd["other_income_streams"]) == 40
+    p = params_from_config(Config(**cfgd))
+    assert p.n_streams == 40 and bool(p.extra_streams)
+    for i, st in enumerate(cfgd["other_income_streams"]):
+        rec = p.stream(i)
+        assert (rec.monthly_amount_today, rec.start_at_age, rec.tax_rate) == (st["monthly_amount_today"], st["start_at_age"], st["tax_rate"])
+        assert rec.duration_years == (-1 if st["duration_years"] is None else st["duration_years"])
+        assert rec.inflation_indexed == int(st["inflation_indexed"])
+    assert lib.mcr_validate_params(C.byref(p)) == 0
+    assert E.query_sizes(p, 49).trajectory_len == 1 + 5 + cfgd["retirement_years"]
+    p.stream(39).monthly_amount_today = -1.0
+    assert lib.mcr_validate_params(C.byref(p)) == -1 and "streams[39]" in N.last_error()
+    few = params_from_config(Config(**dict(cfgd, other_income_streams=cfgd["other_income_streams"][:16])))
+    assert few.n_streams == 16 and not bool(few.extra_streams)
 
 
 def test_no_cpu_fallback(lib):

@@ -43,8 +43,8 @@ def _stream(i, indexed, dur, age, amount=300.0, tax=0.1):
 
 
 def test_sixteen_streams_all_kinds(oracle):
-    """MCR_MAX_STREAMS streams: 11 non-indexed (11 LDS lock columns), finite / zero / infinite durations,
-    start ages before, at and long after retirement, overlapping windows."""
+    """MCR_INLINE_STREAMS streams (the by-value block full): 10 non-indexed (10 LDS lock columns), finite / zero / infinite
+    durations, start ages before, at and long after retirement, overlapping windows.  (Longer lists: test_gpu_many_streams.py.)"""
     streams = [_stream(i, indexed=(i % 3 == 0), dur=[None, 0, 1, 3, 7][i % 5], age=38.0 + 1.75 * i, amount=150.0 + 40 * i, tax=0.05 * (i % 4))
                for i in range(16)]
     cfgd = _base(initial_balance=900_000.0, monthly_contribution=1_000.0, monthly_expenses=5_500.0, retirement_years=25,
@@ -52,8 +52,9 @@ def test_sixteen_streams_all_kinds(oracle):
                  inv2_use_realized_gains_tax_system=True, inv2_realized_gains_tax_rate=0.15, other_income_streams=streams)
     g = _check(oracle, cfgd, wm=30)
     assert 0 < int(g["counters"][0]) < 300  # mixed outcomes: the streams matter
-    with pytest.raises(ValueError):
-        params_from_config(Config(**dict(cfgd, other_income_streams=streams + [_stream(16, True, None, 70.0)])))
+    # a 17th stream is no error (the reference takes any list, config.py:99): it goes behind mcr_params.extra_streams
+    p17 = params_from_config(Config(**dict(cfgd, other_income_streams=streams + [_stream(16, True, None, 70.0)])))
+    assert p17.n_streams == 17 and bool(p17.extra_streams)
 
 
 def test_very_long_horizon(oracle):

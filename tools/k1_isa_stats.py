@@ -21,7 +21,7 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-HEADLINE = "path_kernelILi0ELi0ELi3ELb0ELb0ELi0ELb0E"   # <MODE 0, Philox, both assets taxed, no annual tax, no injection, whole path, unsplit>
+HEADLINE = "path_kernelILi0ELi0ELi3ELb0ELb0ELi0ELb0ELb0E"   # <MODE 0, Philox, both assets taxed, no annual tax, no injection, whole path, unsplit, no extended streams>
 
 
 def classify(op: str) -> str:
