@@ -83,23 +83,47 @@ def host_cpu_info():
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         usable = os.cpu_count() or 1
-    return {"host_cores": os.cpu_count(), "usable_cores": usable, "cpu_model": model}
+    quota = None                        # cgroup v2 CPU quota of this job ("max 100000" = none): cores' worth of time per period
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    return {"host_cores": os.cpu_count(), "usable_cores": usable, "cgroup_cpu_quota_cores": quota, "cpu_model": model}
 
 
-def cpu_baseline_block(params, n_threads: int, paths_per_thread: int, single_thread_paths: int):
-    """`cpu_baseline` of the JSON line: the oracle on `n_threads` host threads (the figure `value` reports) and on ONE
-    thread, the box's core count and CPU model beside them."""
+def cpu_baseline_block(params, n_threads: int, paths_per_thread: int, single_thread_paths: int, all_cores_seconds: float = 10.0):
+    """`cpu_baseline` of the JSON line ("single thread and all cores"): the oracle on ONE thread, on
+    `n_threads` threads (`few_threads`) and on EVERY core this process may run on (`all_cores`, the figure `value` reports: what
+    the host could do), the box's core count, CPU model and cgroup CPU quota beside them.  The all-core sample is sized from
+    a short probe run so that it takes about `all_cores_seconds` whatever the box (bare 256 hardware threads or a cgroup
+    share of them)."""
     info = host_cpu_info()
-    n_threads = max(1, min(int(n_threads), int(info["usable_cores"])))
+    usable = int(info["usable_cores"])
+    n_threads = max(1, min(int(n_threads), usable))
     v1, s1 = cpu_baseline(params, 1, single_thread_paths)
-    v, secs = cpu_baseline(params, n_threads, paths_per_thread)
+    vf, sf = cpu_baseline(params, n_threads, paths_per_thread)
+    few = {"value": vf, "unit": "paths/s", "cores": n_threads,
+           "sample": f"{n_threads} threads x {paths_per_thread} paths ({sf:.1f} s wall)"}
+    if all_cores_seconds > 0 and usable > n_threads:
+        probe_per = max(200, int(v1 * 0.25))                      # ~0.25 s per thread if every thread has a core of its own
+        vp, _ = cpu_baseline(params, usable, probe_per)
+        per = max(probe_per, int(vp * all_cores_seconds / usable))
+        va, sa = cpu_baseline(params, usable, per)
+        allc = {"value": va, "unit": "paths/s", "cores": usable,
+                "sample": f"{usable} threads (every logical core this process may run on) x {per} paths ({sa:.1f} s wall), "
+                          f"sized from a {usable} x {probe_per}-path probe"}
+    else:
+        allc = dict(few, sample=few["sample"] + " (= every usable core)" if usable <= n_threads else few["sample"] + " (all-core run disabled)")
     return {
-        "value": v,
+        "value": allc["value"],
         "unit": "paths/s",
-        "cores": n_threads,
+        "cores": allc["cores"],
         "kind": "port",
-        "sample": f"{n_threads} threads x {paths_per_thread} paths of the same workload "
-                  f"(oracle/mcr_oracle.c, scalar fp64, {secs:.1f} s wall)",
+        "sample": allc["sample"] + " of the same workload (oracle/mcr_oracle.c, scalar fp64, one path range per thread)",
+        "all_cores": allc,
+        "few_threads": few,
         "single_thread": {"value": v1, "unit": "paths/s", "cores": 1,
                           "sample": f"1 thread x {single_thread_paths} paths ({s1:.1f} s wall)"},
         **info,
@@ -108,17 +132,19 @@ def cpu_baseline_block(params, n_threads: int, paths_per_thread: int, single_thr
     }
 
 
-def aux_hbm_kernels(torch, n):
-    """The HBM-side kernels of the path on the BASELINE configs[2] shape (jorge.json + rho=0.3, wm=75:
-    T=48 yearly samples, 40 WR rows), n paths: K1 with full trajectory output (write efficiency), K3
-    row quantiles and K2 histogram (achieved algorithmic GB/s vs the 8 TB/s HBM peak).  Not part of
-    `value`; reported so the memory-bound side of the path has a measured roofline too."""
+def aux_hbm_kernels(torch, n, rho=0.3, allocations=3):
+    """The HBM-side kernels of the path on the BASELINE configs[2] shape (jorge.json, wm=75: T=48 yearly samples,
+    40 WR rows), n paths: K1 with full trajectory output (write efficiency), K3 row quantiles and K2 histogram (achieved
+    algorithmic GB/s vs the 8 TB/s HBM peak).  SURVEY 8(d) B3 asks for the scenario twice: with the
+    equity/inflation correlation of BASELINE's description (rho = 0.3: the `hbm_kernels` block) and AS SHIPPED (the file has
+    no `equity_inflation_correlation` key: rho = None -> the Config default 0.0, backend/config.py:85-90: `hbm_kernels_rho0`).
+    Not part of `value`; reported so the memory-bound side of the path has a measured roofline too."""
     from monte_carlo_retirement_amd import Config, params_from_config
     from monte_carlo_retirement_amd import aggregation as A
     from monte_carlo_retirement_amd import engine as E
 
     with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
-        cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3, seed=12345))
+        cfg = Config(**dict(json.load(fh), seed=12345, **({} if rho is None else {"equity_inflation_correlation": rho})))
     p = params_from_config(cfg)
     b = E.DeviceBatch(p, 75, n, want="full")
     T, ry = b.sizes.trajectory_len, b.sizes.retirement_years
@@ -145,14 +171,14 @@ def aux_hbm_kernels(torch, n):
     # median reported, all three listed.
     k3_by_alloc = [timed(lambda: A.band_quantiles(b, n))]
     fallback_rows = A.last_fallback_rows()
-    for _ in range(2):
+    for _ in range(allocations - 1):
         del b
         torch.cuda.empty_cache()
         b = E.DeviceBatch(p, 75, n, want="full")
         b.launch(12345, 1, 0)
         k3_by_alloc.append(timed(lambda: A.band_quantiles(b, n)))
         fallback_rows = max(fallback_rows, A.last_fallback_rows())
-    ms_k3 = sorted(k3_by_alloc)[1]
+    ms_k3 = sorted(k3_by_alloc)[len(k3_by_alloc) // 2]
     bytes_k3 = 8 * n * (2 * T + ry)      # algorithmic: every entry of the slab has to be read once
     ms_k2 = timed(lambda: A.success_histogram(b.summary["final_balance"], b.success, 100))
     bytes_k2 = 2 * 9 * n                 # min/max pass + bin pass, 8 B value + 1 B flag each
@@ -174,7 +200,9 @@ def aux_hbm_kernels(torch, n):
         except (OSError, KeyError, ValueError):
             continue
     return {
-        "workload": f"BASELINE configs[2] shape: jorge.json rho=0.3, wm=75 (555 months), {n} paths, T={T}, ry={ry}",
+        "workload": f"BASELINE configs[2] shape: jorge.json " + (f"rho={rho}" if rho is not None else "as shipped (rho = 0.0, the Config default)")
+                    + f", wm=75 (555 months), {n} paths, T={T}, ry={ry}",
+        "equity_inflation_correlation": cfg.equity_inflation_correlation,
         "K1_full_output": {"ms": ms_k1, "paths_per_s": n / ms_k1 * 1e3, "algorithmic_write_bytes": bytes_k1,
                            "write_GBps": bytes_k1 / ms_k1 / 1e6, "frac_of_hbm_peak": bytes_k1 / ms_k1 / 1e6 / HBM_PEAK_GBS,
                            "note": "compute-bound: the time-major trajectory stores hide under the fp64 VALU work"},
@@ -196,6 +224,73 @@ def aux_hbm_kernels(torch, n):
                                      "bracketed route)"},
         "K2_histogram": {"ms": ms_k2, "algorithmic_bytes": bytes_k2, "GBps": bytes_k2 / ms_k2 / 1e6},
     }
+
+
+def numpy_stream_block(torch, n, reps=7):
+    """The literal-seed mode (`rng="numpy"`): the reference's OWN random stream reproduced on the device — SeedSequence ->
+    PCG64 -> ziggurat (backend/simulation.py:148-149,195-197,457-458) — so that the same `seed` gives the reference's numbers.
+    config.json scenario, wm=233, n paths, count-only: paths/s of that kernel variant next to the engine's Philox stream's
+    (`value`).  Median of `reps` event-timed launches after two warm-up launches.  Not part of `value`."""
+    from monte_carlo_retirement_amd import Config, params_from_config
+    from monte_carlo_retirement_amd import _native as N
+    from monte_carlo_retirement_amd import engine as E
+
+    with open(os.path.join(REPO, "scenarios", "config.json")) as fh:
+        cfg = Config(**dict(json.load(fh), seed=12345))
+    b = E.DeviceBatch(params_from_config(cfg), WORKING_MONTHS, n, want="count")
+    rng = N.numpy_rng(12345)
+    ts = []
+    for i in range(reps + 2):
+        b.zero_counters()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(); b.launch(rng, 1, 0); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = sorted(ts[2:])[reps // 2]
+    ok, cnt = (int(v) for v in b.counters.cpu().tolist())
+    return {"workload": f"config.json scenario, working_months={WORKING_MONTHS}, {n} paths, success-count only, rng='numpy': "
+                        "SeedSequence(main_seed).spawn -> PCG64 -> ziggurat per path, the reference's own stream (literal seed parity)",
+            "paths": n, "ms": ms, "paths_per_s": n / ms * 1e3, "success_probability": ok / max(1, cnt), "paths_counted": cnt,
+            "kernel": "mcr::path_kernel<0, 1, 3, false, ...> (NumPy-stream variant: sequential generator per lane, no staging)",
+            "note": "the reference's native run of this scenario and seed gives the same per-path flags (tests/test_numpy_rng_gpu.py)"}
+
+
+def class_api_block(torch, n, hbm=None, reps=3):
+    """The drop-in class end to end at the BASELINE configs[2] size: `RetirementMonteCarloSimulator.run_monte_carlo_simulations(75, n)`
+    on jorge.json (rho = 0.3) — the reference's 7-tuple (reference backend/simulation.py:952-1128): n-row summary frame, nominal /
+    real trajectory bands, withdrawal-rate bands, 5 sampled paths, observation counts.  Wall seconds per call (median of `reps`
+    after one untimed call), of which kernels = the path kernel with full output + the band selection as timed in `hbm_kernels`
+    on the same shape; the rest is the 56 B/path summary crossing the host link (on a copy stream, under the band selection),
+    pinned-buffer allocation and frame assembly.  Not part of `value`."""
+    from monte_carlo_retirement_amd import Config
+    from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
+
+    with open(os.path.join(REPO, "scenarios", "jorge.json")) as fh:
+        cfg = Config(**dict(json.load(fh), equity_inflation_correlation=0.3, seed=12345))
+    sim = RetirementMonteCarloSimulator(cfg)
+    sim.use_final_seeds()
+    res = sim.run_monte_carlo_simulations(75, n)          # untimed: first-use allocations (device slab, pinned host buffers)
+    times = []
+    for _ in range(reps):
+        del res
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = sim.run_monte_carlo_simulations(75, n)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    sec = sorted(times)[len(times) // 2]
+    kern = None
+    if hbm and "error" not in hbm:
+        kern = (hbm["K1_full_output"]["ms"] + hbm["K3_row_quantiles"]["ms"]) * 1e-3
+    summary_bytes = 49 * n
+    return {"workload": f"BASELINE configs[2] through the class API: jorge.json rho=0.3, run_monte_carlo_simulations(75, {n}) -> the reference's 7-tuple",
+            "paths": n, "seconds": sec, "all_seconds": times, "paths_per_s": n / sec, "kernel_seconds": kern,
+            "summary_rows": int(len(res[0])), "summary_bytes_device_to_host": summary_bytes,
+            "host_link_GBps_if_the_rest_were_all_transfer": (summary_bytes / max(1e-9, sec - kern) / 1e9) if kern else None,
+            "success_probability_pct": float(res[0]["Success"].mean() * 100.0), "band_rows": int(res[1].shape[0]),
+            "note": "kernel_seconds = K1 full output + K3 bands of the `hbm_kernels` block (same shape, same box, event-timed); the summary "
+                    "download runs on a copy stream under the band selection, the frame is assembled last"}
 
 
 def accuracy_10k():
@@ -452,8 +547,9 @@ def main():
     ap.add_argument("--s60-paths", type=int, default=100_000_000, help="TOTAL paths of the BASELINE configs[3] block (s60)")
     ap.add_argument("--no-search", action="store_true", help="skip the BASELINE configs[4] block (search)")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--cpu-paths-per-thread", type=int, default=160_000)
+    ap.add_argument("--cpu-paths-per-thread", type=int, default=60_000)
     ap.add_argument("--cpu-single-thread-paths", type=int, default=20_000)
+    ap.add_argument("--cpu-all-cores-seconds", type=float, default=10.0, help="target wall time of the all-core oracle run (0 = skip it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -622,7 +718,7 @@ def main():
                 "devices": devices_seen,           # every rank's own report (all_gather_object)
             },
             "roofline": {
-                "kernel": "mcr::path_kernel<0, 0, 3, false, false, 0, false>  (MODE 0 count-only, Philox, realized-gains tax on both assets, no annual tax, unsplit)",
+                "kernel": "mcr::path_kernel<0, 0, 3, false, false, 0, false, false>  (MODE 0 count-only, Philox, realized-gains tax on both assets, no annual tax, unsplit, by-value stream block)",
                 "bound": "valu_fp64",
                 "achieved": achieved_t,
                 "peak": FP64_LANE_OPS_PEAK_T,
@@ -656,12 +752,15 @@ def main():
             out["search"] = search
         if not args.no_aux and world == 1:
             out["hbm_kernels"] = guarded(aux_hbm_kernels, torch, args.aux_paths)
+            out["hbm_kernels_rho0"] = guarded(aux_hbm_kernels, torch, args.aux_paths, rho=None, allocations=1)
+            out["numpy_stream"] = guarded(numpy_stream_block, torch, args.paths)
+            out["class_api_1e7"] = guarded(class_api_block, torch, args.aux_paths, out["hbm_kernels"])
         if not args.no_cpu_baseline:
             # rank 0 only; with N > 1 the other ranks wait at the closing barrier (outside every timed region), so the
             # sample is a quarter of the single-GPU run's
             scale = 1 if world == 1 else 4
             out["cpu_baseline"] = guarded(cpu_baseline_block, params, args.cpu_threads, max(1, args.cpu_paths_per_thread // scale),
-                                          max(1, args.cpu_single_thread_paths // scale))
+                                          max(1, args.cpu_single_thread_paths // scale), args.cpu_all_cores_seconds / scale)
         print(json.dumps(out), flush=True)
     if grouped:
         dist.barrier()

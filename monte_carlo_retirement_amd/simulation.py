@@ -133,23 +133,57 @@ def _gather_columns(rows, picked) -> np.ndarray:
     return torch.stack([rows[:, int(g)] for g in picked]).cpu().numpy()
 
 
+class _SummaryDownload:
+    """summary_df (simulation.py:1012-1027) from a device batch, in two halves so that the transfer overlaps the device
+    work that follows the path kernel.  `start`: the six float columns and the flags go device->host as plain contiguous 1-D
+    copies into ONE pinned [6, n] buffer (no stack / indexing kernel on the device, so the element count any torch kernel sees
+    stays n whatever the batch size) on a COPY STREAM of its own that waits for the path kernel only — 56 bytes a path: 560 MB
+    at 10^7 paths, tens of milliseconds of PCIe time that used to sit, serially, between the path kernel and the band
+    selection (round 3: 131 ms end to end for 77 ms of kernels).  `frame`: waits for the copy stream and wraps the buffer in a
+    no-copy DataFrame with the reference's column order and dtypes."""
+
+    def __init__(self, batch, n: int):
+        torch = batch.torch
+        dev = batch.success.device
+        self.fields = list(_FIELD_OF.items())
+        main = torch.cuda.current_stream(dev)
+        self.stream = _copy_stream(torch, dev)
+        # (the pinned buffers come from torch's caching host allocator: allocated while the path kernel runs)
+        self.host = torch.empty((len(self.fields), n), dtype=torch.float64, pin_memory=True)
+        self.flags = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        self.stream.wait_stream(main)                    # = after the path kernel that was just enqueued
+        with torch.cuda.stream(self.stream):
+            for i, (_, f) in enumerate(self.fields):
+                self.host[i].copy_(batch.summary[f][:n], non_blocking=True)
+            self.flags.copy_(batch.success[:n], non_blocking=True)
+        self._batch = batch                               # the source tensors stay alive until the copies have run
+
+    def frame(self) -> pd.DataFrame:
+        self.stream.synchronize()
+        self._batch = None
+        h = self.host.numpy()
+        cols = {name: h[i] for i, (name, _) in enumerate(self.fields)}
+        cols["Success"] = self.flags.numpy().view(np.bool_)
+        return pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS}, copy=False)
+
+
+_copy_streams: Dict[Tuple[int, int], object] = {}
+
+
+def _copy_stream(torch, dev):
+    """One side stream per (thread, device) for device->host transfers that overlap kernels on the caller's stream."""
+    import threading
+
+    key = (threading.get_ident(), dev.index or 0)
+    st = _copy_streams.get(key)
+    if st is None:
+        st = _copy_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _summary_frame(batch, n: int) -> pd.DataFrame:
-    """summary_df (simulation.py:1012-1027) from a device batch: the six float columns and the flags go device->host
-    as plain contiguous 1-D copies into ONE pinned [6, n] buffer (no stack / indexing kernel on the device, so the
-    element count any torch kernel sees stays n whatever the batch size), then a no-copy DataFrame with the
-    reference's column order and dtypes."""
-    torch = batch.torch
-    fields = list(_FIELD_OF.items())
-    host = torch.empty((len(fields), n), dtype=torch.float64, pin_memory=True)
-    for i, (_, f) in enumerate(fields):
-        host[i].copy_(batch.summary[f][:n], non_blocking=True)
-    flags = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-    flags.copy_(batch.success[:n], non_blocking=True)
-    torch.cuda.current_stream(batch.success.device).synchronize()
-    h = host.numpy()
-    cols = {name: h[i] for i, (name, _) in enumerate(fields)}
-    cols["Success"] = flags.numpy().view(np.bool_)
-    return pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS}, copy=False)
+    """The whole download in one call (callers with nothing to overlap it with)."""
+    return _SummaryDownload(batch, n).frame()
 
 
 def sample_columns(seed: int, n: int, k: int):
@@ -220,6 +254,8 @@ class RetirementMonteCarloSimulator:
         #: instead of all-gathering it into the host memory of every rank.  Everything else of the 7-tuple (bands, sampled
         #: paths, observation counts) is identical on all ranks either way; `results.compact_result` needs no per-path frame.
         self.gather_all_max_paths = 20_000_000
+        #: which ranks hold the rows of the last sharded run's `summary_df`: "all", or "rank0" (a deliberate empty frame elsewhere)
+        self.last_summary_scope = "all"
         # NumPy stream bookkeeping: children spawned so far per stream, and the offset at which each
         # (stream, n) batch was spawned — the reference's _path_seed_cache rule (:154, :192-199)
         self._np_children_spawned = {"search": 0, "final": 0}
@@ -413,8 +449,10 @@ class RetirementMonteCarloSimulator:
         # pandas draws them with RandomState(seed).choice(n, 5, replace=False), which permutes all n indices — 7 ms at 1e6
         # paths, as long as the kernel itself.  It is host-only work: done HERE, while the (asynchronous) launch runs.
         picked = self._sample_columns(n)
-
-        summary_df = _summary_frame(batch, n)
+        # Device -> host of the per-path summary (56 B / path) on the copy stream, behind the path kernel only; the band
+        # selection (K3) is enqueued on the main stream right after and runs while the summary crosses the host link; the
+        # frame is built last (the reference builds it first, simulation.py:1012-1027: same values, another order of work)
+        download = _SummaryDownload(batch, n)
 
         traj_q, real_q, wr_q, wr_counts = A.band_quantiles(batch, n)
         qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
@@ -428,6 +466,7 @@ class RetirementMonteCarloSimulator:
         if picked is not None:
             sample_trajectories_list = _gather_columns(batch.trajectory, picked).tolist()
             sample_real_trajectories_list = _gather_columns(batch.real_trajectory, picked).tolist()
+        summary_df = download.frame()
         return (
             summary_df,
             trajectory_percentiles_df,
@@ -453,7 +492,10 @@ class RetirementMonteCarloSimulator:
         per-path summary is all-gathered (49 B/path; above `gather_all_max_paths` paths: gathered to rank 0 only,
         the reference's `summary_df` contract being a single-process one, simulation.py:1012-1027), the quantile bands come from the distributed radix
         select (digit histograms summed across ranks), the sampled paths are contributed by the rank that
-        owns them.  Every rank returns the same 7-tuple, bit-identical to the single-GPU result."""
+        owns them.  Every rank returns the same bands, sampled paths and observation counts, bit-identical to the single-GPU
+        result; `summary_df` is the single-GPU frame on every rank up to `gather_all_max_paths` paths and, above that, on rank 0
+        ONLY — the other ranks then return a frame with the reference's columns and NO rows, and
+        `self.last_summary_scope == "rank0"` tells such a caller that the empty frame is deliberate ("all" otherwise)."""
         import torch
         import torch.distributed as dist
 
@@ -475,14 +517,18 @@ class RetirementMonteCarloSimulator:
             local[len(fields), :count] = batch.success[:count].to(torch.float64)
         local = local.to(comm)
         to_rank0_only = n > self.gather_all_max_paths
+        self.last_summary_scope = "rank0" if to_rank0_only else "all"
         if to_rank0_only:
             logger.warning(f"{n} paths over {world} ranks: the per-path summary frame goes to rank 0 only "
                            f"(gather_all_max_paths = {self.gather_all_max_paths}); the other ranks return an empty frame")
             gathered = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-            dist.gather(local, gathered, dst=0)
+            pending = dist.gather(local, gathered, dst=0, async_op=True)
         else:
             gathered = [torch.empty_like(local) for _ in range(world)]
-            dist.all_gather(gathered, local)
+            pending = dist.all_gather(gathered, local, async_op=True)
+        # ---- bands: enqueued while the summary gather is in flight (the selection's own small collectives queue behind it) ----
+        traj_q, real_q, wr_q, wr_counts = D.sharded_band_quantiles(batch, count)
+        pending.wait()
         del local
         if gathered is None:
             summary_df = pd.DataFrame({c: pd.Series(dtype=bool if c == "Success" else np.float64) for c in SUMMARY_COLUMNS})
@@ -493,8 +539,6 @@ class RetirementMonteCarloSimulator:
             cols = {name: allf[i] for i, name in enumerate(_FIELD_OF.keys())}
             cols["Success"] = allf[len(fields)] != 0.0
             summary_df = pd.DataFrame({c: cols[c] for c in SUMMARY_COLUMNS})
-        # ---- bands ----
-        traj_q, real_q, wr_q, wr_counts = D.sharded_band_quantiles(batch, count)
         qcols = pd.Index(list(A.TRAJECTORY_QUANTILES), dtype="float64")
         trajectory_percentiles_df = pd.DataFrame(traj_q, columns=qcols)
         real_trajectory_percentiles_df = pd.DataFrame(real_q, columns=qcols)

@@ -28,7 +28,7 @@ def _run(*args, timeout=600):
 def test_bench_self_launches_two_ranks():
     n, steps = 200_000, 3
     out = _run("--gpus", "2", "--backend", "gloo", "--steps", str(steps), "--warmup", "1", "--paths", str(n), "--s60-paths", "300001",
-               "--cpu-threads", "2", "--cpu-paths-per-thread", "4000", "--cpu-single-thread-paths", "4000")
+               "--cpu-threads", "2", "--cpu-paths-per-thread", "4000", "--cpu-single-thread-paths", "4000", "--cpu-all-cores-seconds", "0")
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["unit"] == "paths/s"
     assert "all-reduce" in out["config"]["parallelism"] and "x2" in out["config"]["parallelism"]
     assert out["paths_counted"] == 2 * steps * n            # the exchange sums every rank's steps exactly once
@@ -60,14 +60,29 @@ def test_bench_self_launches_two_ranks():
 
 def test_bench_single_gpu_line_has_the_contract_keys():
     out = _run("--steps", "3", "--warmup", "1", "--paths", "200000", "--aux-paths", "2200000", "--s60-paths", "400000",
-               "--cpu-threads", "4", "--cpu-paths-per-thread", "2000", "--cpu-single-thread-paths", "2000")
+               "--cpu-threads", "4", "--cpu-paths-per-thread", "2000", "--cpu-single-thread-paths", "2000", "--cpu-all-cores-seconds", "1.5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "hbm_kernels", "s60", "s60_data_ranged", "search"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "hbm_kernels", "hbm_kernels_rho0", "numpy_stream", "class_api_1e7",
+              "s60", "s60_data_ranged", "search"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["dtype"] == "f64" and out["vs_baseline"] is None and out["paths_counted"] == 3 * 200000
+    # the CPU side "single thread and all cores"; `value` is the all-core figure
     cb = out["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 4 and cb["value"] > cb["single_thread"]["value"] > 0
+    assert cb["kind"] == "port" and cb["few_threads"]["cores"] == 4 and cb["few_threads"]["value"] > cb["single_thread"]["value"] > 0
     assert cb["host_cores"] >= cb["usable_cores"] >= 4 and isinstance(cb["cpu_model"], str) and cb["cpu_model"]
+    assert cb["all_cores"]["cores"] == cb["usable_cores"] == cb["cores"] and cb["value"] == cb["all_cores"]["value"] > cb["single_thread"]["value"]
+    assert "cgroup_cpu_quota_cores" in cb
+    # jorge.json with rho = 0.3 AND as shipped (rho = 0); the literal-seed stream has a timed figure
+    assert out["hbm_kernels"]["equity_inflation_correlation"] == 0.3 and out["hbm_kernels_rho0"]["equity_inflation_correlation"] == 0.0
+    for blk in ("hbm_kernels", "hbm_kernels_rho0"):
+        assert "error" not in out[blk], out[blk]
+        assert out[blk]["K1_full_output"]["paths_per_s"] > 0 and out[blk]["K3_row_quantiles"]["rows"] == 136
+    ns = out["numpy_stream"]
+    assert "error" not in ns, ns
+    assert ns["paths_counted"] == 200000 and ns["paths_per_s"] > 0 and 0.9 < ns["success_probability"] <= 1.0
+    ca = out["class_api_1e7"]
+    assert "error" not in ca, ca
+    assert ca["paths"] == 2200000 and ca["seconds"] > ca["kernel_seconds"] > 0 and ca["summary_rows"] == 2200000
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_of_measured_issue_ceiling"}
     assert out["s60"]["paths_counted"] == 400000 and out["hbm_kernels"]["K3_row_quantiles"]["rows"] == 136
     k3 = out["hbm_kernels"]["K3_row_quantiles"]
