@@ -625,9 +625,6 @@ __global__ __launch_bounds__(1024) void rq_tiny_kernel(const double* __restrict_
     if (t == 0) { rq_make_intervals(B, qlo, qhi, args.n_q, kRqCoarseSubBits); B.open_lo = open_lo; B.open_hi = open_hi; }
 }
 
-#ifdef MCR_RQ_EXPERIMENT
-__device__ double g_rq_sigmas = 4.5;   // timing experiments only: narrower fine brackets = fewer candidates (rows may then take the radix route)
-#endif
 struct RqRefineShared {
     unsigned long long below[kRqMaxQ], upto[kRqMaxQ], qlo[kRqMaxQ], qhi[kRqMaxQ];
     unsigned int miss;
@@ -834,14 +831,7 @@ __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))
 template <int P>
 __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void rq_slab_kernel(const double* __restrict__ rows, int64_t row_stride, int64_t n,
                                                           RqBracket* br, unsigned int* hist, int sub_bits, int max_q, double* cand,
-                                                          unsigned int cand_cap
-#ifdef MCR_RQ_EXPERIMENT
-                                                          , int dbg     // timing experiments only (tools/k3_slab_parts.sh): parts of the element loop switched off, results invalid
-#endif
-                                                          ) {
-#ifndef MCR_RQ_EXPERIMENT
-    constexpr int dbg = 0;
-#endif
+                                                          unsigned int cand_cap) {
     constexpr int kStage = 192;                          // candidates a wave stages in LDS between two flushes
     typedef double d2_t __attribute__((ext_vector_type(2)));
     __shared__ unsigned long long bound[P];              // key bounds (sub-bin arithmetic of the staged candidates)
@@ -911,20 +901,16 @@ __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))
     auto flush = [&]() {
         if (filled == 0u) return;
         unsigned int base = 0u;
-        if (!(dbg & (2 | 64))) {
-            if (lane == 0) base = atomicAdd(&B.cand_count, filled);
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-        }
-        if (dbg & 64) base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned int)kStage;      // (experiment: no atomic, a fixed region per wave)
+        if (lane == 0) base = atomicAdd(&B.cand_count, filled);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
         for (unsigned int i = lane; i < filled; i += 64u) {
             const double x = wstage[i] + 0.0;                   // -0.0 -> +0.0 (see rq_bound_value)
-            if (!(dbg & 4)) tally(x);
+            tally(x);
             // (the few writes of the pass — 4 % of its bytes — cost it a fifth of its read rate: a property of mixed streams on
-            //  this part, tools/ubench/hbm_read.hip "S" lines; nontemporal stores help the bare sweep by 6 % and this call not at all)
-            if (!(dbg & (2 | 32)) && base + i < cand_cap) {
-                if (dbg & 128) __builtin_nontemporal_store(x, &crow[base + i]);
-                else crow[base + i] = x;
-            }
+            //  this part, tools/ubench/hbm_read.hip "S" lines; nontemporal stores help the bare sweep by 6 % and this call not at
+            //  all.  The part-by-part timing of this kernel — staging / atomic / stores / tally switched off one at a time — was
+            //  an experiment build of round 3: profiles/r03/k3_slab_parts.txt, LABNOTES.md)
+            if (base + i < cand_cap) crow[base + i] = x;
         }
         filled = 0u;
     };
@@ -942,7 +928,7 @@ __global__ __launch_bounds__(kRqBlock) __attribute__((amdgpu_waves_per_eu(5, 8))
             mask[u] = __ballot(oks[u] && ((keep >> pos) & 1u));            // (trash is even or beyond the keep bits: never a member)
             total += (unsigned int)__popcll(mask[u]);
         }
-        if (total == 0u || (dbg & 1)) return;
+        if (total == 0u) return;
         if (total > (unsigned int)kStage) {
             // more than a stage of members in one batch (a wide interval / a giant tie straddling a bound): straight to the row's buffer
             flush();
@@ -1091,11 +1077,7 @@ __device__ void rq_refine_row(int row, int64_t m, const RqArgs& args, const RqBr
         } else {
             const double q = args.q[t];
             const double vi = (double)(mv - 1) * q;
-#ifdef MCR_RQ_EXPERIMENT
-            const double d = ceil(g_rq_sigmas * sqrt((double)mv * q * (1.0 - q))) + 2.0;   // (experiment: MCR_RQ_SIGMAS)
-#else
             const double d = ceil(kRqBracketSigmas * sqrt((double)mv * q * (1.0 - q))) + 2.0;
-#endif
             const double rl = floor(vi) - d, rh = floor(vi) + 1.0 + d;
             const int b = B1.interval_of_q[t];
             const unsigned long long lo_b = B1.lo[b], hi_b = B1.hi[b];
@@ -1690,13 +1672,6 @@ static void rq_opt_in_lds(int device) {
     lds_opt_in_device = device;
 }
 
-#ifdef MCR_RQ_EXPERIMENT
-// -DMCR_RQ_EXPERIMENT builds (csrc/build.py build(variant="exp", ...), never the shipped library): MCR_RQ_DBG switches parts
-// of rq_slab_kernel off to time what is left — 1 no staging of bracket members, 2 flush without the global atomic and the
-// candidate stores, 4 flush without the sub-histogram tally, 32 flush without the stores, 64 flush without the atomic, 128 nontemporal candidate stores (a valid pass)
-static int rq_dbg() { const char* e = std::getenv("MCR_RQ_DBG"); return e ? std::atoi(e) : 0; }
-#endif
-
 // One counting pass over the first `len` entries of every row.
 static void rq_count_pass(hipStream_t s, const double* rows, int64_t row_stride, int32_t n_rows, int64_t len, RqBracket* br,
                           unsigned int* hist, int sub_bits, bool compact, int n_q, double* bcand, unsigned int bcap) {
@@ -1721,14 +1696,8 @@ static void rq_count_pass(hipStream_t s, const double* rows, int64_t row_stride,
     if (skip) {
         const size_t lds2 = (size_t)(kRqBlock / 64) * 192 * sizeof(double) + (size_t)(2 * max_q + 2) * kRqBlock * sizeof(unsigned int) +
                             (size_t)max_q * ((size_t)1 << sub_bits) * sizeof(unsigned int);
-#ifdef MCR_RQ_EXPERIMENT
-        const int dbg = rq_dbg();
-        if (small_p) hipLaunchKernelGGL((rq_slab_kernel<16>), grid, block, lds2, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap, dbg);
-        else hipLaunchKernelGGL((rq_slab_kernel<32>), grid, block, lds2, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap, dbg);
-#else
         if (small_p) hipLaunchKernelGGL((rq_slab_kernel<16>), grid, block, lds2, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap);
         else hipLaunchKernelGGL((rq_slab_kernel<32>), grid, block, lds2, s, rows, row_stride, len, br, hist, sub_bits, max_q, bcand, bcap);
-#endif
     }
 }
 
@@ -1929,14 +1898,8 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     //  one process: G = 1 2.262 ms, G = 2 2.345, G = 3 2.478, G = 4 2.717 — cross-stream event waits cost more than the
     //  0.35 ms of small kernels they were meant to hide.)
     hipError_t e = hipSuccess;
-#ifdef MCR_RQ_EXPERIMENT
-    { const char* e = std::getenv("MCR_RQ_SIGMAS"); const double sg = e ? std::atof(e) : 4.5; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rq_sigmas), &sg, sizeof(sg), 0, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); }
-#endif
     head(s, 0, n_rows, L.fb_count);
     slab(s, 0, n_rows);
-#ifdef MCR_RQ_EXPERIMENT
-    if ((rq_dbg() & ~128) != 0) { (void)hipStreamSynchronize(s); return MCR_OK; }   // the slab pass's counts are invalid: nothing may consume them (128 alone is a valid pass)
-#endif
     tail(s, 0, n_rows);
     // (6) rows the brackets could not decide (a target outside its bracket, candidates overflowing on a wide tie
     //     that straddles a bracket end, a sample without data) take the full passes.  How many is only known on the

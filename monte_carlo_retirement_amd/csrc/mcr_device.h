@@ -3,9 +3,13 @@
 // One simulated path lives in ONE LANE: the monthly state (two balances, two cost bases, two
 // gain accumulators, the price level, the contribution) stays in VGPRs for the whole horizon;
 // scenario parameters are wave-uniform kernel arguments (SGPRs).  All arithmetic is IEEE fp64
-// and the translation unit is compiled with -ffp-contract=off so every a*b+c rounds twice, as
-// in the reference (CPython floats).  Each function cites the reference lines it replaces
-// (rflamino/monte_carlo_retirement, backend/simulation.py).
+// and the translation unit is compiled with -ffp-contract=off: the STATE MACHINE's a*b+c rounds
+// twice, as in the reference (CPython floats); FMAs appear only where they are spelled out
+// (__builtin_fma / inline v_fma_f64): inside exp / log / sincos, the Newton steps of the
+// divisions, and the log-returns a + b z of monthly_gross / growth_rows2 (one rounding there
+// instead of the reference's two, 1e-16 |x| on the argument of exp: part of the 1e-9 budget).
+// Each function cites the reference lines it replaces (rflamino/monte_carlo_retirement,
+// backend/simulation.py).
 //
 // Data-dependent branches of the reference (sell inv1 / sell inv2, early-outs) are written
 // branch-free with selected operands: the lanes of a wavefront diverge on them almost every

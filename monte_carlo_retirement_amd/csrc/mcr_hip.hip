@@ -101,11 +101,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
-#ifdef MCR_K1_FORCE_SELECTS
-    constexpr bool MM = false;           // (A/B builds only)
-#else
     constexpr bool MM = !SPLIT;          // exec-masked moves (issue-bound launches) vs the compiler's selects (latency-bound SPLIT launches): MCR_MASKED_MOVE, mcr_device.h
-#endif
     constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
     const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
     const bool producer = SPLIT && threadIdx.x >= (unsigned)kBlock;                  // wave-uniform (kBlock = 4 wavefronts)
@@ -937,9 +933,6 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d, std::vec
     d->any_annual_tax = (d->annual_rate1 > 0.0) || (d->annual_rate2 > 0.0);
     d->any_real_rate = (d->real_rate1 > 0.0) || (d->real_rate2 > 0.0);
     d->tax_mask = (d->real_rate1 > 0.0 ? 1 : 0) | (d->real_rate2 > 0.0 ? 2 : 0);
-#ifdef MCR_K1_COARSE_TAX   // (A/B builds only: round 2's taxed / untaxed variants)
-    if (d->tax_mask) d->tax_mask = 3;
-#endif
     const double sqrt12 = std::sqrt((double)kMPY);
     d->a1 = p->inv1_mu_log / (double)kMPY;   d->b1 = p->inv1_sigma_log / sqrt12;     // :473
     d->ainf = p->inf_mu_log / (double)kMPY;  d->binf = p->inf_sigma_log / sqrt12;

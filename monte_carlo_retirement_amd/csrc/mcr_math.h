@@ -20,9 +20,10 @@
 // PATH = true (template parameter of fexp / neg2_log_u32 / sincos_u32; used by growth_rows2, i.e. inside the month loop
 // only): the series are cut where their truncation error is still far inside the 1e-9 path tolerance — exp with r^2/24
 // replaced by its zero-mean fit a^2/40 (|error| <= 3.5e-15 relative, mean 0), the logarithm's series at r^4 (r^5 and r^6 terms, <= 3.6e-13 absolute, dropped), cos
-// without dl^6/720 (<= 4.7e-15 absolute): 7.5 instructions per path-month less (7.04 -> 6.85 ms per 1e6 paths), worst
-// path-level error against the oracle 7e-11 of the 1e-9 allowed (2e5 paths x 3 scenarios, 0 Success flags flipped;
-// tools/k1_accuracy.py).  The unit-function entry points and the shock-row API keep the full forms.
+// without dl^6/720 (<= 4.7e-15 absolute): 7.5 instructions per path-month less (7.00 -> 6.81 ms per 1e6 paths), worst
+// path-level error against the oracle 1.6e-11 of the 1e-9 allowed, relative to the path's money scale (4 x 2e6 paths, 0 Success
+// flags flipped; profiles/r03/k1_accuracy_2e6_paths.txt, tools/k1_accuracy.py).  The unit-function entry points and the
+// shock-row API keep the full forms.
 // (All bounds measured on the device: tests/test_gpu_math.py.)
 // Tables are correctly rounded (tools/gen_tables.py) and staged in LDS once per workgroup.
 #pragma once
@@ -161,13 +162,9 @@ __device__ __forceinline__ void sincos_u32(uint32_t x, const double* tab, const 
     const double S = tab[kTabSinCos + 2 * k], C = tab[kTabSinCos + 2 * k + 1];
     const double dl = __builtin_fma((double)(x & 0x00FFFFFFu), kAngleScale, R.ang_bias);  // |dl| <= pi/256
     const double d2 = dl * dl;
-    // (dropping sin's dl^5/120 <= 2.3e-12 as well was measured: 3.3 instead of 2.8 % faster, path error 2.4e-10 of the 1e-9
-    //  allowed on 2e5 paths — too little margin for longer soaks; `MCR_MATH_TRIM_SIN` builds that experiment)
-#ifdef MCR_MATH_TRIM_SIN
-    const double sd = PATH ? __builtin_fma(dl * d2, R.sin_c6, dl) : __builtin_fma(dl * d2, __builtin_fma(d2, 1.0 / 120.0, R.sin_c6), dl);
-#else
+    // (dropping sin's dl^5/120 <= 2.3e-12 as well was measured in round 3: 3.3 instead of 2.8 % faster, path error 2.4e-10 of
+    //  the 1e-9 allowed on 2e5 paths — too little margin for longer soaks: not taken, LABNOTES.md)
     const double sd = __builtin_fma(dl * d2, __builtin_fma(d2, 1.0 / 120.0, R.sin_c6), dl);  // sin(dl)
-#endif
     double cp;
     if (PATH) {                                   // path form: dl^6/720 <= 4.7e-15 dropped
         cp = __builtin_fma(d2, R.cos_c24, -0.5);

@@ -55,7 +55,7 @@ def test_bench_self_launches_two_ranks():
     assert sr["final_run_paths"] == 1_000_000 and 90.0 < sr["final_success_probability_pct"] < 100.0
     # rank 0 times the CPU baseline under N > 1 too
     cb = out["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["host_cores"] >= 1 and cb["single_thread"]["cores"] == 1
+    assert cb["kind"] == "port" and cb["few_threads"]["cores"] == 2 and cb["host_cores"] >= 1 and cb["single_thread"]["cores"] == 1
 
 
 def test_bench_single_gpu_line_has_the_contract_keys():
@@ -70,8 +70,9 @@ def test_bench_single_gpu_line_has_the_contract_keys():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["few_threads"]["cores"] == 4 and cb["few_threads"]["value"] > cb["single_thread"]["value"] > 0
     assert cb["host_cores"] >= cb["usable_cores"] >= 4 and isinstance(cb["cpu_model"], str) and cb["cpu_model"]
-    assert cb["all_cores"]["cores"] == cb["usable_cores"] == cb["cores"] and cb["value"] == cb["all_cores"]["value"] > cb["single_thread"]["value"]
-    assert "cgroup_cpu_quota_cores" in cb
+    assert cb["all_cores"]["cores"] == cb["usable_cores"] and cb["all_cores"]["value"] > 0
+    assert cb["value"] == max(cb["all_cores"]["value"], cb["few_threads"]["value"]) > cb["single_thread"]["value"]
+    assert "cgroup_cpu_quota_cores" in cb and cb["quota_limited"] == (cb["cgroup_cpu_quota_cores"] is not None and cb["cgroup_cpu_quota_cores"] < cb["usable_cores"])
     # jorge.json with rho = 0.3 AND as shipped (rho = 0); the literal-seed stream has a timed figure
     assert out["hbm_kernels"]["equity_inflation_correlation"] == 0.3 and out["hbm_kernels_rho0"]["equity_inflation_correlation"] == 0.0
     for blk in ("hbm_kernels", "hbm_kernels_rho0"):
