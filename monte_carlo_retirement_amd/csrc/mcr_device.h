@@ -39,6 +39,7 @@ constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SI
 struct DevStream {
     double amount;        // monthly_amount_today
     double keep;          // 1.0 - tax_rate                      (simulation.py:675-677)
+    double amount_keep;   // amount * keep: the tolerance form of the month nets the amount first ((a k) price instead of (a price) k)
     int32_t start_month;  // stream_payment_start_month_index    (:47-63, :603-608)
     int32_t end_month;    // start + duration_years*12, INT32_MAX for None (:609-613, :653-656)
     int32_t indexed;      // inflation_indexed
@@ -87,6 +88,14 @@ struct LaneParams {
 };
 __device__ __forceinline__ LaneParams lane_params(const DevParams& P) {
     LaneParams L{P.alloc1, P.alloc2, P.real_rate1, P.real_rate2};
+    asm volatile("" : "+v"(L.alloc1), "+v"(L.alloc2), "+v"(L.real_rate1), "+v"(L.real_rate2));
+    return L;
+}
+// The tolerance form of the month (below) selects the seller's rate and the seller's weight x rate; it needs neither weight
+// on its own (the drift of asset 2 is minus the drift of asset 1).  In the SAME struct, so that the helpers keep one
+// signature: alloc1 / alloc2 then hold the products.
+__device__ __forceinline__ LaneParams lane_params_tol(const DevParams& P) {
+    LaneParams L{P.alloc1 * P.real_rate1, P.alloc2 * P.real_rate2, P.real_rate1, P.real_rate2};
     asm volatile("" : "+v"(L.alloc1), "+v"(L.alloc2), "+v"(L.real_rate1), "+v"(L.real_rate2));
     return L;
 }
@@ -502,10 +511,103 @@ __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TOLERANCE FORM of the month (the forms the path kernel runs since round 4; the forms above stay the unit API and the A/B
+// build -DMCR_K1_EXACT_MONTH).  The forms above mirror the reference's roundings operation by operation; the stated
+// tolerance of the path is 1e-9, six orders above one rounding, so inside the month loop the same quantities are computed
+// as the hardware likes them:
+//   * every a * b + c is ONE fused multiply-add (spelled __builtin_fma: the translation unit stays -ffp-contract=off, the
+//     values are the same in every kernel variant);
+//   * a quotient is numerator x reciprocal (v_rcp_f64 + one Newton step: 2^-50), without the residual correction that made
+//     it the correctly rounded a / b (2 FMAs per quotient, 11 quotients a retirement month);
+//   * algebra the reference spells out is folded: tax = gross x gain_fraction x rate (the max(0, gross - basis_removed) of
+//     :235 / :314 IS gross x gain_fraction), net = gross x (1 - gain_fraction x rate); the drift of asset 2 is minus the
+//     drift of asset 1 (:328); a proportional sale leaves an asset's gain fraction unchanged, so the month's rebalance
+//     takes the seller's from the withdrawal that has just computed it (:301 / :329 after :221).
+// Every difference is a relative perturbation of ~1e-16 per operation — what a rounding is; measured against the oracle
+// (profiles/r04/k1_accuracy_*.txt): worst path-level error relative to the path's money scale, flips of Success flags.
+template <bool T1, bool T2 = T1, bool MM = true>
+__device__ __forceinline__ void net_liquidation_values2_tol(double b1, double c1, double r1, double b2, double c2, double r2,
+                                                            double& v1, double& v2) {
+    v1 = b1; v2 = b2;
+    if (T1) v1 = __builtin_fma(-fmax(0.0, b1 - c1), r1, b1);     // :266-272
+    if (T2) v2 = __builtin_fma(-fmax(0.0, b2 - c2), r2, b2);
+    if (b1 <= kEps) { MCR_MASKED_MOVE; v1 = 0.0; }
+    if (b2 <= kEps) { MCR_MASKED_MOVE; v2 = 0.0; }
+}
+// (:201-254)  gf_out: the asset's gain fraction max(0, bal - cb) / bal — valid whenever bal > eps; the month's rebalance reuses it
+template <bool TAXED>
+__device__ __forceinline__ WithdrawCand withdraw_arith_tol(double bal, double cb, double net_target, double rate, double& gf_out) {
+    WithdrawCand w;
+    const double y = recip_nr<false>(bal);
+    gf_out = 0.0;
+    if (TAXED) {
+        const double gf = fmax(0.0, bal - cb) * y;                       // :221
+        const double nf0 = __builtin_fma(-gf, rate, 1.0);                // :222-226
+        w.gross = fmin(net_target * recip_nr<false>(fmax(kEps, nf0)), bal);   // :227-231
+        w.net = w.gross * nf0;                                           // :235-241: gross - (gross gf) rate
+        gf_out = gf;
+    } else {
+        w.gross = fmin(net_target, bal);
+        w.net = w.gross;
+    }
+    const double fraction_sold = w.gross * y;                            // :233
+    w.nb = bal - w.gross;                                                // :243
+    w.ncb = __builtin_fma(-cb, fraction_sold, cb);                       // :234, :244
+    return w;
+}
+template <bool T1, bool T2 = T1, bool MM = true>
+__device__ __forceinline__ void withdraw2_tol(double& b1, double& c1, double t1, double r1, double& g1, double& n1,
+                                              double& b2, double& c2, double t2, double r2, double& g2, double& n2,
+                                              double& gf1, double& gf2) {
+    WithdrawCand w1 = withdraw_arith_tol<T1>(b1, c1, t1, r1, gf1);
+    WithdrawCand w2 = withdraw_arith_tol<T2>(b2, c2, t2, r2, gf2);
+    withdraw_fixup<MM>(w1, b1, c1, t1, g1, n1);
+    withdraw_fixup<MM>(w2, b2, c2, t2, g2, n2);
+}
+// (:274-359)  L = lane_params_tol(P): L.alloc1 / L.alloc2 hold weight x rate.  HAVE_GF: gf1 / gf2 are the assets' gain
+// fractions (from this month's withdrawals); otherwise the seller's is computed here.
+template <bool TAXED, bool HAVE_GF, bool MM = true>
+__device__ __forceinline__ void rebalance_tol(const DevParams& P, const LaneParams& L, double& b1, double& c1, double& b2, double& c2,
+                                              double gf1 = 0.0, double gf2 = 0.0) {
+    const double total = b1 + b2;                                  // :288
+    const double drift1 = __builtin_fma(-total, P.alloc1, b1);     // :293-294
+    if ((total > kEps) && (fabs(drift1) > kEps)) {                 // :290-296
+        MCR_MASKED_MOVE;
+        const bool sell1 = drift1 > 0.0;                           // :298
+        const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;   // seller
+        const double drift = fabs(drift1);                         // :328: b2 - total (1 - alloc1) = -(b1 - total alloc1)
+        const double y = recip_nr<false>(bs);
+        double gross_sale, net_purchase;
+        if (TAXED) {
+            const double rate_s = sell1 ? L.real_rate1 : L.real_rate2;
+            const double ar_s = sell1 ? L.alloc1 : L.alloc2;       // the SOLD asset's own weight (:309,:337) x its rate
+            const double gf = HAVE_GF ? (sell1 ? gf1 : gf2) : fmax(0.0, bs - cs) * y;   // :301 / :329
+            const double denom = fmax(kEps, __builtin_fma(-gf, ar_s, 1.0));             // :302-310
+            gross_sale = fmin(bs, drift * recip_nr<false>(denom)); // :311
+            net_purchase = __builtin_fma(-gross_sale, gf * rate_s, gross_sale);         // :314-320
+        } else {
+            gross_sale = fmin(bs, drift);
+            net_purchase = gross_sale;
+        }
+        const double fraction_sold = gross_sale * y;               // :312
+        const double nbs = bs - gross_sale;                        // :322
+        const double ncs = __builtin_fma(-cs, fraction_sold, cs);  // :313, :323
+        double r1b = b1 + net_purchase, r1c = c1 + net_purchase;   // :324-325 for the buyer; the seller's pair is replaced below
+        double r2b = b2 + net_purchase, r2c = c2 + net_purchase;
+        if (sell1) { MCR_MASKED_MOVE; r1b = nbs; r1c = ncs; }
+        else { MCR_MASKED_MOVE; r2b = nbs; r2c = ncs; }
+        if (r1b <= kEps) { MCR_MASKED_MOVE; r1b = 0.0; r1c = 0.0; }  // :355-358
+        if (r2b <= kEps) { MCR_MASKED_MOVE; r2b = 0.0; r2c = 0.0; }
+        b1 = r1b; c1 = r1c; b2 = r2b; c2 = r2c;
+    }
+}
+
 // _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
 // ANNUAL = false: compile-time variant for scenarios in which no asset is on the annual-gains system (annual
 // bill identically 0, :380-390): the block below and the monthly gain accumulators are dead code.
-template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true, bool T1 = TAXED, bool T2 = TAXED, bool MM = true>
+// TOL: the closing rebalance in its tolerance form (then L = lane_params_tol(P)).
+template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true, bool T1 = TAXED, bool T2 = TAXED, bool MM = true, bool TOL = false>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
                                                   double& b2, double& c2, double gain1, double gain2) {
     bool tax_failed = false;
@@ -528,17 +630,23 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         }
     }
     if (STRICT) rebalance<true, TAXED, MM>(L, b1, c1, b2, c2);  // :432-442 (always)
+    else if (TOL) rebalance_tol<TAXED, false, MM>(P, L, b1, c1, b2, c2);
     else rebalance_path<TAXED, MM>(L, b1, c1, b2, c2);
     return tax_failed;
 }
 
 // Market step shared by both phases (:522-538 and :695-714), given the month's gross factors.
-template <bool ANNUAL = true>
+template <bool ANNUAL = true, bool TOL = false>
 __device__ __forceinline__ void market_step(double g1, double ginf, double g2, double& b1, double& b2,
                                             double& gacc1, double& gacc2, double& infl) {
     if (ANNUAL) {                     // the accumulators only feed the annual tax bill
-        gacc1 += b1 * (g1 - 1.0);     // :534
-        gacc2 += b2 * (g2 - 1.0);     // :535
+        if (TOL) {
+            gacc1 = __builtin_fma(b1, g1 - 1.0, gacc1);
+            gacc2 = __builtin_fma(b2, g2 - 1.0, gacc2);
+        } else {
+            gacc1 += b1 * (g1 - 1.0);     // :534
+            gacc2 += b2 * (g2 - 1.0);     // :535
+        }
     }
     b1 *= g1;                         // :536
     b2 *= g2;                         // :537

@@ -101,6 +101,15 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
+#ifdef MCR_K1_EXACT_MONTH
+    constexpr bool TOL = false;          // A/B build: the state machine mirrors the reference's roundings operation by operation
+#else
+    constexpr bool TOL = true;           // the month in its tolerance form (mcr_device.h: "TOLERANCE FORM of the month")
+#endif
+#ifndef MCR_K1_REUSE_GF
+#define MCR_K1_REUSE_GF 1
+#endif
+    constexpr bool kReuseGf = MCR_K1_REUSE_GF != 0;
     constexpr bool MM = !SPLIT;          // exec-masked moves (issue-bound launches) vs the compiler's selects (latency-bound SPLIT launches): MCR_MASKED_MOVE, mcr_device.h
     constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
     const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         g2 = ginf * monthly_gross(P.aprem, P.bprem, zp, tab);  // :532
     };
 
-    const LaneParams L = lane_params(P);
+    const LaneParams L = TOL ? lane_params_tol(P) : lane_params(P);
 
     // ---- initial state (:490-510) ----
     double b1 = P.initial_balance * P.alloc1;  // :499
@@ -299,13 +308,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         begin_month(m - 1);
         double g1, ginf, g2;
         growth(m - 1, g1, ginf, g2);                                   // :519-532
-        market_step<ANNUAL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl); // :534-538
+        market_step<ANNUAL, TOL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl); // :534-538
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        rebalance_path<TANY, MM>(L, b1, c1, b2, c2);                   // :549-553
+        if (TOL) rebalance_tol<TANY, false, MM>(P, L, b1, c1, b2, c2); // :549-553
+        else rebalance_path<TANY, MM>(L, b1, c1, b2, c2);
         if (m % kMPY == 0) {                                           // :557
-            pre_fail |= annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
+            pre_fail |= annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM, TOL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
             put_sample(t_idx++, b1 + b2, infl);                        // :574-576
             gacc1 = 0.0; gacc2 = 0.0;                                  // :578-579
         }
@@ -330,8 +340,13 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         if (P.n_streams > 0) S0 = P.streams[0];
         if (P.n_streams > 1) S1 = P.streams[1];
         // (opaque to the compiler from here on: kernel-argument loads are otherwise rematerialised in the loop)
-        asm volatile("" : "+s"(S0.amount), "+s"(S0.keep), "+s"(S0.start_month), "+s"(S0.end_month), "+s"(S0.indexed), "+s"(S0.lock_slot));
-        asm volatile("" : "+s"(S1.amount), "+s"(S1.keep), "+s"(S1.start_month), "+s"(S1.end_month), "+s"(S1.indexed), "+s"(S1.lock_slot));
+        if (TOL) {   // (the tolerance form of the month reads the netted amount only)
+            asm volatile("" : "+s"(S0.amount_keep), "+s"(S0.start_month), "+s"(S0.end_month), "+s"(S0.indexed), "+s"(S0.lock_slot));
+            asm volatile("" : "+s"(S1.amount_keep), "+s"(S1.start_month), "+s"(S1.end_month), "+s"(S1.indexed), "+s"(S1.lock_slot));
+        } else {
+            asm volatile("" : "+s"(S0.amount), "+s"(S0.keep), "+s"(S0.start_month), "+s"(S0.end_month), "+s"(S0.indexed), "+s"(S0.lock_slot));
+            asm volatile("" : "+s"(S1.amount), "+s"(S1.keep), "+s"(S1.start_month), "+s"(S1.end_month), "+s"(S1.indexed), "+s"(S1.lock_slot));
+        }
     }
     int ruin_bin = pre_fail ? 0 : -1;
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
@@ -350,22 +365,27 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                 if (kStaged) growth(wm + rmi, g1, ginf, g2);           // staged factors: the LDS reads are issued early
                 const double price = infl;                             // :644
                 const double expenses = P.monthly_expenses * price;    // :645-647
-                double income = 0.0;                                   // :649
+                // exact form: income accumulates (:649-677) and need = max(0, expenses - income); tolerance form: `income` runs
+                // DOWN from the expenses, one FMA per indexed stream ((amount keep) price), one subtraction per frozen stream
+                // (its slot holds the netted amount): need = max(0, what is left)
+                double income = TOL ? expenses : 0.0;                  // :649
                 auto stream_income = [&](const DevStream& S) {
                     if (rmi < S.start_month || rmi >= S.end_month) return;    // :653-658
-                    double nominal;
+                    double nominal = 0.0;
                     if (S.indexed) {
+                        if (TOL) { income = __builtin_fma(-S.amount_keep, price, income); return; }
                         nominal = S.amount * price;                    // :661-665
                     } else if (!XS || S.lock_slot < P.n_lock_slots) {      // (wave-uniform; without XS every slot is an LDS column)
                         double* slot = lock_lds + (size_t)S.lock_slot * kBlock + tid;
-                        if (rmi == S.start_month) *slot = S.amount * price;  // :667-671 (first active month)
+                        if (rmi == S.start_month) *slot = (TOL ? S.amount_keep : S.amount) * price;  // :667-671 (first active month)
                         nominal = *slot;                               // :672-674
                     } else {                                           // a slot beyond the LDS budget: the lane's column of the overflow block
                         double* slot = P.lock_overflow + (size_t)(S.lock_slot - P.n_lock_slots) * (size_t)P.lock_stride + (size_t)local;
-                        if (rmi == S.start_month) *slot = S.amount * price;
+                        if (rmi == S.start_month) *slot = (TOL ? S.amount_keep : S.amount) * price;
                         nominal = *slot;
                     }
-                    income += nominal * S.keep;                        // :675-677
+                    if (TOL) income -= nominal;
+                    else income += nominal * S.keep;                   // :675-677
                 };
                 int s = 0;
                 if (SPLIT) {            // the first two streams sit in SGPRs for the whole launch (see S0, S1 above)
@@ -378,26 +398,48 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     const DevStreamTable xs = (DevStreamTable)P.extra_streams;
                     for (int x = 0; x < P.n_extra_streams; ++x) {
                         DevStream S;
-                        S.amount = xs[x].amount; S.keep = xs[x].keep; S.start_month = xs[x].start_month;
+                        S.amount = xs[x].amount; S.keep = xs[x].keep; S.amount_keep = xs[x].amount_keep; S.start_month = xs[x].start_month;
                         S.end_month = xs[x].end_month; S.indexed = xs[x].indexed; S.lock_slot = xs[x].lock_slot;
                         stream_income(S);
                     }
                 }
-                const double need = fmax(0.0, expenses - income);      // :679-682
+                const double need = fmax(0.0, TOL ? income : expenses - income);      // :679-682
                 bool stop = false;
                 if (b1 + b2 <= kEps && need > kEps) {                  // :684-690 (FAIL-1, no shock consumed)
                     yfail = true; stop = true;
                 }
                 if (!stop) {
                     if (!kStaged) growth(wm + rmi, g1, ginf, g2);      // :692-705 (sequential generators draw here)
-                    market_step<ANNUAL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl);  // :706-714
+                    market_step<ANNUAL, TOL>(g1, ginf, g2, b1, b2, gacc1, gacc2, infl);  // :706-714
                     if (b1 + b2 <= kEps && need > kEps) {              // :717-724 (FAIL-2)
                         MCR_MASKED_MOVE;                              // keep it a branch: no lane takes it in most months
                         b1 = fmax(0.0, b1); b2 = fmax(0.0, b2);
                         yfail = true; stop = true;
                     }
                 }
-                if (!stop) {
+                if (!stop && TOL) {
+                    double cap1, cap2;
+                    net_liquidation_values2_tol<T1, T2, MM>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
+                    const double cap = cap1 + cap2;                                   // :738
+                    const double target = fmin(need, cap);                            // :739-742
+                    if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
+                    double prop1 = cap1 * recip_nr<false>(cap);                       // :750-754
+                    if (!(cap > kEps)) { MCR_MASKED_MOVE; prop1 = P.alloc1; }
+                    const double t1 = target * prop1, t2 = target - t1;               // :755: target (1 - prop1)
+                    double gw1, nw1, gw2, nw2, gf1, gf2;
+                    withdraw2_tol<T1, T2, MM>(b1, c1, t1, L.real_rate1, gw1, nw1, b2, c2, t2, L.real_rate2, gw2, nw2, gf1, gf2);  // :757-776
+                    tg1 += gw1;                                                       // :766
+                    tg2 += gw2;                                                       // :777
+                    if (kSummary) treal = __builtin_fma((gw1 + gw2) * infl_ret, recip_nr<false>(fmax(price, kEps)), treal);  // :778-782
+                    if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
+                    rebalance_tol<TANY, kReuseGf, MM>(P, L, b1, c1, b2, c2, gf1, gf2);    // :792-796
+                    if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
+                        const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM, true>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
+                        gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
+                        yfail = yfail || tf;                                          // :821-822
+                    }
+                }
+                if (!stop && !TOL) {
                     double cap1, cap2;
                     net_liquidation_values2<T1, T2, MM>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
                     const double cap = cap1 + cap2;                                   // :738
@@ -458,7 +500,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
         if (succeeded) {
-            const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
+            const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM, TOL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :880-893
             if (tf) {                                                            // :894-896
                 succeeded = false; ruin_bin = ry + 1;
                 if (kSumLds) sum_col[2 * kBlock] = (double)ry; else ytr_bits = f64_bits((double)ry);
@@ -958,6 +1000,7 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d, std::vec
         DevStream& o = s < MCR_INLINE_STREAMS ? d->streams[s] : (extra ? (*extra)[(size_t)(s - MCR_INLINE_STREAMS)] : scratch);
         o.amount = in.monthly_amount_today;
         o.keep = 1.0 - in.tax_rate;  // :676
+        o.amount_keep = o.amount * o.keep;
         o.start_month = start_month_index(p->current_age, wm, in.start_at_age);  // :603-608
         if (in.duration_years < 0) {
             o.end_month = INT32_MAX;  // None: forever (:654)

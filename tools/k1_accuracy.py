@@ -10,7 +10,7 @@ from oracle import oracle as O
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 golden = json.load(open(os.path.join(root, "tests", "golden", "paths_injected.json")))
 n = int(os.environ.get("K1_ACC_PATHS", "200000"))
-for name in ("C1_config_json_wm233", "S60_wm120", "ANNUAL_wm50"):
+for name in os.environ.get("K1_ACC_SCENARIOS", "C1_config_json_wm233,S60_wm120,ANNUAL_wm50,MIXED_wm36,FAILING_wm24").split(","):
     g = [x for x in golden if x["name"] == name][0]
     p = params_from_config(Config(**g["cfg"]))
     sid = {"search": 0, "final": 1}[g["stream"]]
@@ -22,12 +22,14 @@ for name in ("C1_config_json_wm233", "S60_wm120", "ANNUAL_wm50"):
     [t.start() for t in ths]; [t.join() for t in ths]
     cpu = {k: np.concatenate([q[k] for q in parts]) for k in E.SUMMARY_FIELDS + ("success",)}
     scale = np.maximum(np.abs(cpu["start_balance"]), 1.0)
-    worst = 0.0
+    worst, med = 0.0, 0.0
     for k in E.SUMMARY_FIELDS:
         both = np.isnan(gpu[k]) & np.isnan(cpu[k])
         err = np.where(both, 0.0, np.abs(gpu[k] - cpu[k])) / np.maximum(np.abs(np.nan_to_num(cpu[k])), scale)
         worst = max(worst, float(np.nanmax(err)))
-    print(f"{name:24s} {n} paths: worst scaled error {worst:.3e}  flipped flags {int((gpu['success'] != cpu['success']).sum())}")
+        med = max(med, float(np.nanmedian(err)))
+    print(f"{name:24s} {n} paths: worst scaled error {worst:.3e}  (largest per-field median {med:.1e})  flipped flags {int((gpu['success'] != cpu['success']).sum())}"
+          f"  success {int(cpu['success'].sum())}", flush=True)
 cfg = Config(**dict(json.load(open(os.path.join(root, "scenarios", "config.json"))), seed=12345))
 b = E.DeviceBatch(params_from_config(cfg), 233, 1_000_000, want="count")
 ts = []
