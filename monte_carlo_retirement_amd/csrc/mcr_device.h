@@ -70,6 +70,8 @@ struct DevParams {
     int32_t any_annual_tax;            // annual_rate1 > 0 || annual_rate2 > 0
     int32_t any_real_rate;             // real_rate1 > 0 || real_rate2 > 0
     int32_t tax_mask;                  // bit 0: real_rate1 > 0, bit 1: real_rate2 > 0  -> selects the TAXED kernel variant (0 .. 3)
+    int32_t exact_month;               // a realized-gains rate above 1 - 1e-6: the reference's denominator clamps can bind -> exact forms, generic variants
+    int32_t reserved_;
     DevStream streams[MCR_INLINE_STREAMS];
     // other_income_streams beyond the by-value block (the list has any length, config.py:99)
     int32_t n_extra_streams;           // records in `extra_streams`
@@ -512,64 +514,58 @@ __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// TOLERANCE FORM of the month (the forms the path kernel runs since round 4; the forms above stay the unit API and the A/B
-// build -DMCR_K1_EXACT_MONTH).  The forms above mirror the reference's roundings operation by operation; the stated
-// tolerance of the path is 1e-9, six orders above one rounding, so inside the month loop the same quantities are computed
-// as the hardware likes them:
-//   * every a * b + c is ONE fused multiply-add (spelled __builtin_fma: the translation unit stays -ffp-contract=off, the
-//     values are the same in every kernel variant);
-//   * a quotient is numerator x reciprocal (v_rcp_f64 + one Newton step: 2^-50), without the residual correction that made
-//     it the correctly rounded a / b (2 FMAs per quotient, 11 quotients a retirement month);
-//   * algebra the reference spells out is folded: tax = gross x gain_fraction x rate (the max(0, gross - basis_removed) of
-//     :235 / :314 IS gross x gain_fraction), net = gross x (1 - gain_fraction x rate); the drift of asset 2 is minus the
-//     drift of asset 1 (:328); a proportional sale leaves an asset's gain fraction unchanged, so the month's rebalance
-//     takes the seller's from the withdrawal that has just computed it (:301 / :329 after :221).
-// Every difference is a relative perturbation of ~1e-16 per operation — what a rounding is; measured against the oracle
+// TOLERANCE FORM of the month (what the path kernel runs since round 4; the forms above stay the unit API, the corner
+// configurations below and the A/B build -DMCR_K1_EXACT_MONTH).  The forms above mirror the reference's roundings operation
+// by operation; the stated tolerance of the path is 1e-9, six orders above one rounding, so inside the month loop the same
+// quantities are computed from the CLOSED FORM of the reference's formulas, fused multiply-adds and uncorrected reciprocals
+// (v_rcp_f64 + one Newton step, 2^-50):
+//
+//  withdrawal (:726-790).  With G_i = max(0, b_i - c_i) the liquidation value is cap_i = b_i - r_i G_i (:256-272), the asset's
+//    net fraction 1 - gf_i r_i = cap_i / b_i (:221-227), and its net target t_i = target cap_i / cap (:750-765).  Hence
+//        gross_i = t_i / (cap_i / b_i) = b_i (target / cap):
+//    BOTH assets sell the same fraction phi = target / cap of their balance, basis and gain (:233-244):
+//        b_i <- b_i (1 - phi),  c_i <- c_i (1 - phi),  net cash = phi cap = target,  gross = phi (b1 + b2).
+//    One reciprocal (of cap) instead of five, no per-asset quotient; the net-cash test (:784-790) IS the capacity test
+//    (:743-748).  min(gross, bal) (:228-231) is phi <= 1.
+//  rebalance (:274-359).  With G = max(0, bs - cs) of the seller, gross_sale = drift / (1 - a_s r_s G / bs) and
+//    fraction_sold = gross_sale / bs (:301-312) are ONE quotient: fraction_sold = drift / (bs - a_s r_s G); the tax is
+//    fraction_sold G r_s (:314-319: max(0, gross - basis_removed) IS fraction_sold G); the drift of asset 2 is minus the
+//    drift of asset 1 (:328).
+//
+// Validity: the reference clamps its denominators at 1e-6 (:227, :307-310).  1 - gf r >= 1 - r and 1 - a gf r >= 1 - r, so
+// with both effective realized-gains rates <= 1 - 1e-6 the clamps never bind and the closed form is the reference's
+// arithmetic up to roundings (DevParams::exact_month = 0, derive_params).  Configurations with a rate above that (a 100 % tax
+// on realized gains) run the exact forms in the generic kernel variants.  One sub-case is resolved differently: alive, total
+// balance > 1e-6 but total liquidation value <= 1e-6 (needs a balance below 1e-6 / (1 - r) dollars in the very month the path
+// fails): the reference sells target x weight from each asset (:750-755), the closed form sells nothing — at most
+// 1e-6 / (1 - r) dollars in the failing year's residual sample.
+// Every other difference is a relative perturbation of ~1e-16 per operation — what a rounding is; measured against the oracle
 // (profiles/r04/k1_accuracy_*.txt): worst path-level error relative to the path's money scale, flips of Success flags.
+
+// liquidation values (:256-272, :726-737); returns cap1 + cap2
 template <bool T1, bool T2 = T1, bool MM = true>
-__device__ __forceinline__ void net_liquidation_values2_tol(double b1, double c1, double r1, double b2, double c2, double r2,
-                                                            double& v1, double& v2) {
-    v1 = b1; v2 = b2;
-    if (T1) v1 = __builtin_fma(-fmax(0.0, b1 - c1), r1, b1);     // :266-272
+__device__ __forceinline__ double capacity_tol(double b1, double c1, double r1, double b2, double c2, double r2) {
+    double v1 = b1, v2 = b2;
+    if (T1) v1 = __builtin_fma(-fmax(0.0, b1 - c1), r1, b1);
     if (T2) v2 = __builtin_fma(-fmax(0.0, b2 - c2), r2, b2);
     if (b1 <= kEps) { MCR_MASKED_MOVE; v1 = 0.0; }
     if (b2 <= kEps) { MCR_MASKED_MOVE; v2 = 0.0; }
+    return v1 + v2;
 }
-// (:201-254)  gf_out: the asset's gain fraction max(0, bal - cb) / bal — valid whenever bal > eps; the month's rebalance reuses it
-template <bool TAXED>
-__device__ __forceinline__ WithdrawCand withdraw_arith_tol(double bal, double cb, double net_target, double rate, double& gf_out) {
-    WithdrawCand w;
-    const double y = recip_nr<false>(bal);
-    gf_out = 0.0;
-    if (TAXED) {
-        const double gf = fmax(0.0, bal - cb) * y;                       // :221
-        const double nf0 = __builtin_fma(-gf, rate, 1.0);                // :222-226
-        w.gross = fmin(net_target * recip_nr<false>(fmax(kEps, nf0)), bal);   // :227-231
-        w.net = w.gross * nf0;                                           // :235-241: gross - (gross gf) rate
-        gf_out = gf;
-    } else {
-        w.gross = fmin(net_target, bal);
-        w.net = w.gross;
-    }
-    const double fraction_sold = w.gross * y;                            // :233
-    w.nb = bal - w.gross;                                                // :243
-    w.ncb = __builtin_fma(-cb, fraction_sold, cb);                       // :234, :244
-    return w;
+// both assets sell the fraction phi (:757-776 as derived above)
+template <bool MM = true>
+__device__ __forceinline__ void sell_fraction_tol(double phi, double& b1, double& c1, double& b2, double& c2) {
+    double nb1 = __builtin_fma(-b1, phi, b1), nc1 = __builtin_fma(-c1, phi, c1);     // :243-244
+    double nb2 = __builtin_fma(-b2, phi, b2), nc2 = __builtin_fma(-c2, phi, c2);
+    if (nb1 <= kEps) { MCR_MASKED_MOVE; nb1 = 0.0; nc1 = 0.0; }                       // :245-247
+    if (nb2 <= kEps) { MCR_MASKED_MOVE; nb2 = 0.0; nc2 = 0.0; }
+    if (b1 <= kEps) { MCR_MASKED_MOVE; nb1 = b1; nc1 = c1; }                         // :218-219: an asset without a balance is left alone
+    if (b2 <= kEps) { MCR_MASKED_MOVE; nb2 = b2; nc2 = c2; }
+    b1 = nb1; c1 = nc1; b2 = nb2; c2 = nc2;
 }
-template <bool T1, bool T2 = T1, bool MM = true>
-__device__ __forceinline__ void withdraw2_tol(double& b1, double& c1, double t1, double r1, double& g1, double& n1,
-                                              double& b2, double& c2, double t2, double r2, double& g2, double& n2,
-                                              double& gf1, double& gf2) {
-    WithdrawCand w1 = withdraw_arith_tol<T1>(b1, c1, t1, r1, gf1);
-    WithdrawCand w2 = withdraw_arith_tol<T2>(b2, c2, t2, r2, gf2);
-    withdraw_fixup<MM>(w1, b1, c1, t1, g1, n1);
-    withdraw_fixup<MM>(w2, b2, c2, t2, g2, n2);
-}
-// (:274-359)  L = lane_params_tol(P): L.alloc1 / L.alloc2 hold weight x rate.  HAVE_GF: gf1 / gf2 are the assets' gain
-// fractions (from this month's withdrawals); otherwise the seller's is computed here.
-template <bool TAXED, bool HAVE_GF, bool MM = true>
-__device__ __forceinline__ void rebalance_tol(const DevParams& P, const LaneParams& L, double& b1, double& c1, double& b2, double& c2,
-                                              double gf1 = 0.0, double gf2 = 0.0) {
+// (:274-359)  L = lane_params_tol(P): L.alloc1 / L.alloc2 hold weight x rate of asset 1 / 2.
+template <bool TAXED, bool MM = true>
+__device__ __forceinline__ void rebalance_tol(const DevParams& P, const LaneParams& L, double& b1, double& c1, double& b2, double& c2) {
     const double total = b1 + b2;                                  // :288
     const double drift1 = __builtin_fma(-total, P.alloc1, b1);     // :293-294
     if ((total > kEps) && (fabs(drift1) > kEps)) {                 // :290-296
@@ -577,21 +573,18 @@ __device__ __forceinline__ void rebalance_tol(const DevParams& P, const LanePara
         const bool sell1 = drift1 > 0.0;                           // :298
         const double bs = sell1 ? b1 : b2, cs = sell1 ? c1 : c2;   // seller
         const double drift = fabs(drift1);                         // :328: b2 - total (1 - alloc1) = -(b1 - total alloc1)
-        const double y = recip_nr<false>(bs);
-        double gross_sale, net_purchase;
+        double fraction_sold, net_purchase;
         if (TAXED) {
             const double rate_s = sell1 ? L.real_rate1 : L.real_rate2;
             const double ar_s = sell1 ? L.alloc1 : L.alloc2;       // the SOLD asset's own weight (:309,:337) x its rate
-            const double gf = HAVE_GF ? (sell1 ? gf1 : gf2) : fmax(0.0, bs - cs) * y;   // :301 / :329
-            const double denom = fmax(kEps, __builtin_fma(-gf, ar_s, 1.0));             // :302-310
-            gross_sale = fmin(bs, drift * recip_nr<false>(denom)); // :311
-            net_purchase = __builtin_fma(-gross_sale, gf * rate_s, gross_sale);         // :314-320
+            const double G = fmax(0.0, bs - cs);                   // :301 / :329 (x bs)
+            fraction_sold = fmin(1.0, drift * recip_nr<false>(__builtin_fma(-ar_s, G, bs)));   // :302-312
+            net_purchase = fraction_sold * __builtin_fma(-G, rate_s, bs);                       // :314-320: gross - (fraction G) rate
         } else {
-            gross_sale = fmin(bs, drift);
-            net_purchase = gross_sale;
+            fraction_sold = fmin(1.0, drift * recip_nr<false>(bs));
+            net_purchase = fraction_sold * bs;
         }
-        const double fraction_sold = gross_sale * y;               // :312
-        const double nbs = bs - gross_sale;                        // :322
+        const double nbs = __builtin_fma(-bs, fraction_sold, bs);  // :322
         const double ncs = __builtin_fma(-cs, fraction_sold, cs);  // :313, :323
         double r1b = b1 + net_purchase, r1c = c1 + net_purchase;   // :324-325 for the buyer; the seller's pair is replaced below
         double r2b = b2 + net_purchase, r2c = c2 + net_purchase;
@@ -603,9 +596,6 @@ __device__ __forceinline__ void rebalance_tol(const DevParams& P, const LanePara
     }
 }
 
-// _apply_annual_gain_taxes (:361-450).  Returns tax_failed.
-// ANNUAL = false: compile-time variant for scenarios in which no asset is on the annual-gains system (annual
-// bill identically 0, :380-390): the block below and the monthly gain accumulators are dead code.
 // TOL: the closing rebalance in its tolerance form (then L = lane_params_tol(P)).
 template <bool STRICT = true, bool TAXED = true, bool ANNUAL = true, bool T1 = TAXED, bool T2 = TAXED, bool MM = true, bool TOL = false>
 __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const LaneParams& L, double& b1, double& c1,
@@ -630,7 +620,7 @@ __device__ __forceinline__ bool annual_gain_taxes(const DevParams& P, const Lane
         }
     }
     if (STRICT) rebalance<true, TAXED, MM>(L, b1, c1, b2, c2);  // :432-442 (always)
-    else if (TOL) rebalance_tol<TAXED, false, MM>(P, L, b1, c1, b2, c2);
+    else if (TOL) rebalance_tol<TAXED, MM>(P, L, b1, c1, b2, c2);
     else rebalance_path<TAXED, MM>(L, b1, c1, b2, c2);
     return tax_failed;
 }

@@ -93,7 +93,15 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // other_income_streams has no length limit in the reference, config.py:99).  A compile-time variant because the headline
 // kernels have no SGPR to spare for the two extra tests a month; instantiated for the generic tax form only (TAXED = 3,
 // ANNUAL = true: exact zeros for a zero rate, like the NumPy-stream variants).
-template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false, bool XS = false>
+// EXACT = true: the month in its exact-rounding forms (mcr_device.h) instead of the tolerance form — for configurations whose
+// realized-gains rate lets the reference's denominator clamps bind (DevParams::exact_month), instantiated for the generic XS
+// variants only; -DMCR_K1_EXACT_MONTH builds a library that runs every variant that way (A/B).
+#ifdef MCR_K1_EXACT_MONTH
+constexpr bool kExactMonthDefault = true;
+#else
+constexpr bool kExactMonthDefault = false;
+#endif
+template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false, bool XS = false, bool EXACT = kExactMonthDefault>
 __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
@@ -101,15 +109,8 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
-#ifdef MCR_K1_EXACT_MONTH
-    constexpr bool TOL = false;          // A/B build: the state machine mirrors the reference's roundings operation by operation
-#else
-    constexpr bool TOL = true;           // the month in its tolerance form (mcr_device.h: "TOLERANCE FORM of the month")
-#endif
-#ifndef MCR_K1_REUSE_GF
-#define MCR_K1_REUSE_GF 1
-#endif
-    constexpr bool kReuseGf = MCR_K1_REUSE_GF != 0;
+    static_assert(!EXACT || XS || kExactMonthDefault, "the exact month is instantiated for the generic variants only");
+    constexpr bool TOL = !EXACT;         // the month in its tolerance form (mcr_device.h: "TOLERANCE FORM of the month")
     constexpr bool MM = !SPLIT;          // exec-masked moves (issue-bound launches) vs the compiler's selects (latency-bound SPLIT launches): MCR_MASKED_MOVE, mcr_device.h
     constexpr int kThreads = SPLIT ? 2 * kBlock : kBlock;
     const int tid = SPLIT ? (int)(threadIdx.x & (kBlock - 1)) : (int)threadIdx.x;    // the path's lane column in every per-path LDS array
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         const double k1 = contrib * P.alloc1;                          // :540-542
         const double k2 = contrib - k1;                                // :543
         b1 += k1; c1 += k1; b2 += k2; c2 += k2;                        // :544-547
-        if (TOL) rebalance_tol<TANY, false, MM>(P, L, b1, c1, b2, c2); // :549-553
+        if (TOL) rebalance_tol<TANY, MM>(P, L, b1, c1, b2, c2);        // :549-553
         else rebalance_path<TANY, MM>(L, b1, c1, b2, c2);
         if (m % kMPY == 0) {                                           // :557
             pre_fail |= annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM, TOL>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :558-573
@@ -418,21 +419,19 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     }
                 }
                 if (!stop && TOL) {
-                    double cap1, cap2;
-                    net_liquidation_values2_tol<T1, T2, MM>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);  // :726-737
-                    const double cap = cap1 + cap2;                                   // :738
+                    // the withdrawal in closed form (mcr_device.h): both assets sell the fraction target / capacity
+                    const double cap = capacity_tol<T1, T2, MM>(b1, c1, L.real_rate1, b2, c2, L.real_rate2);   // :726-738
                     const double target = fmin(need, cap);                            // :739-742
-                    if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3)
-                    double prop1 = cap1 * recip_nr<false>(cap);                       // :750-754
-                    if (!(cap > kEps)) { MCR_MASKED_MOVE; prop1 = P.alloc1; }
-                    const double t1 = target * prop1, t2 = target - t1;               // :755: target (1 - prop1)
-                    double gw1, nw1, gw2, nw2, gf1, gf2;
-                    withdraw2_tol<T1, T2, MM>(b1, c1, t1, L.real_rate1, gw1, nw1, b2, c2, t2, L.real_rate2, gw2, nw2, gf1, gf2);  // :757-776
-                    tg1 += gw1;                                                       // :766
-                    tg2 += gw2;                                                       // :777
-                    if (kSummary) treal = __builtin_fma((gw1 + gw2) * infl_ret, recip_nr<false>(fmax(price, kEps)), treal);  // :778-782
-                    if (need > kEps && nw1 + nw2 < need - kEps) yfail = true;         // :784-790 (FAIL-4)
-                    rebalance_tol<TANY, kReuseGf, MM>(P, L, b1, c1, b2, c2, gf1, gf2);    // :792-796
+                    if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3) = :784-790 (FAIL-4): the net cash is the target
+                    double phi = target * recip_nr<false>(cap);                       // :750-765
+                    if (!(cap > kEps)) { MCR_MASKED_MOVE; phi = 0.0; }
+                    if (kSummary) {
+                        const double gross = phi * (b1 + b2);                         // :766, :777: gross withdrawals of the month
+                        tg1 += gross;
+                        treal = __builtin_fma(gross * infl_ret, recip_nr<false>(fmax(price, kEps)), treal);  // :778-782
+                    }
+                    sell_fraction_tol<MM>(phi, b1, c1, b2, c2);                       // :757-776
+                    rebalance_tol<TANY, MM>(P, L, b1, c1, b2, c2);                    // :792-796
                     if (!yfail && (wm + rmi + 1) % kMPY == 0) {                       // :798-804
                         const bool tf = annual_gain_taxes<false, TANY, ANNUAL, T1, T2, MM, true>(P, L, b1, c1, b2, c2, gacc1, gacc2);  // :805-818
                         gacc1 = 0.0; gacc2 = 0.0;                                     // :819-820
@@ -975,6 +974,9 @@ static int derive_params(const mcr_params* p, int32_t wm, DevParams* d, std::vec
     d->any_annual_tax = (d->annual_rate1 > 0.0) || (d->annual_rate2 > 0.0);
     d->any_real_rate = (d->real_rate1 > 0.0) || (d->real_rate2 > 0.0);
     d->tax_mask = (d->real_rate1 > 0.0 ? 1 : 0) | (d->real_rate2 > 0.0 ? 2 : 0);
+    // the tolerance form of the month is the reference's arithmetic while its denominator clamps (max(1e-6, 1 - gf r), :227,
+    // :307-310) cannot bind: both effective rates <= 1 - 1e-6 (mcr_device.h).  Otherwise: exact forms, generic variants.
+    d->exact_month = (d->real_rate1 > 1.0 - kEps || d->real_rate2 > 1.0 - kEps) ? 1 : 0;
     const double sqrt12 = std::sqrt((double)kMPY);
     d->a1 = p->inv1_mu_log / (double)kMPY;   d->b1 = p->inv1_sigma_log / sqrt12;     // :473
     d->ainf = p->inf_mu_log / (double)kMPY;  d->binf = p->inf_sigma_log / sqrt12;
@@ -1148,19 +1150,22 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     size_t lds = 0;
     rc = plan_path_kernel_lds(d, mode, np_rng, injected != nullptr, split, io.out.hist_n_bins, &lds);
     if (rc != MCR_OK) return rc;
-    if (split && (d.n_lock_slots < d.n_lock_slots_total || d.n_extra_streams > 0)) {
+    if (split && (d.n_lock_slots < d.n_lock_slots_total || d.n_extra_streams > 0 || (d.exact_month && !kExactMonthDefault))) {
         // the producer / consumer form doubles the stage: where only IT cannot hold every lock column, the unsplit kernel runs
         split = false;
         rc = plan_path_kernel_lds(d, mode, np_rng, false, false, io.out.hist_n_bins, &lds);
         if (rc != MCR_OK) return rc;
     }
     // XS: records beyond the by-value block and / or lock slots beyond the LDS budget -> the extended-stream variants
-    const bool xs = d.n_lock_slots < d.n_lock_slots_total || d.n_extra_streams > 0;
+    //     (and configurations that need the exact month: the generic variants carry both forms of it)
+    const bool exact = d.exact_month && !kExactMonthDefault;
+    const bool xs = d.n_lock_slots < d.n_lock_slots_total || d.n_extra_streams > 0 || exact;
     StreamSideBlock side;
     rc = side.attach(d, extra, grid.x, stream);
     if (rc != MCR_OK) { (void)side.release(stream); return rc; }
     if (xs) {
-#define MCR_LAUNCH_X(M, R, I) hipLaunchKernelGGL((path_kernel<M, R, 3, true, I, 0, false, true>), grid, block, lds, stream, d, io, (const DevParams*)nullptr)
+#define MCR_LAUNCH_X(M, R, I) do { if (exact) hipLaunchKernelGGL((path_kernel<M, R, 3, true, I, 0, false, true, true>), grid, block, lds, stream, d, io, (const DevParams*)nullptr); \
+                                   else hipLaunchKernelGGL((path_kernel<M, R, 3, true, I, 0, false, true>), grid, block, lds, stream, d, io, (const DevParams*)nullptr); } while (0)
         if (injected) MCR_LAUNCH_X(2, 0, true);
         else if (!np_rng) { if (mode == 2) MCR_LAUNCH_X(2, 0, false); else if (mode == 1) MCR_LAUNCH_X(1, 0, false); else MCR_LAUNCH_X(0, 0, false); }
         else { if (mode == 2) MCR_LAUNCH_X(2, 1, false); else if (mode == 1) MCR_LAUNCH_X(1, 1, false); else MCR_LAUNCH_X(0, 1, false); }
@@ -1279,7 +1284,7 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
     DevParams& top = blocks[(size_t)n_cand - 1];
     // (stream lists beyond the by-value block, or lock slots beyond the LDS of the split form, take one launch per candidate:
     //  each then carries its own device table / overflow block)
-    if (top.n_extra_streams > 0) return MCR_ERR_UNSUPPORTED;
+    if (top.n_extra_streams > 0 || (top.exact_month && !kExactMonthDefault)) return MCR_ERR_UNSUPPORTED;
     size_t lds = 0;
     if (plan_path_kernel_lds(top, 0, false, false, true, 0, &lds) != MCR_OK || top.n_lock_slots < top.n_lock_slots_total) return MCR_ERR_UNSUPPORTED;
     for (DevParams& b : blocks) b.n_lock_slots = top.n_lock_slots;
