@@ -186,6 +186,30 @@ def _summary_frame(batch, n: int) -> pd.DataFrame:
     return _SummaryDownload(batch, n).frame()
 
 
+class _BackgroundCall:
+    """`fn(*args)` on a host thread of its own; `result()` joins and returns its value or re-raises its exception."""
+
+    def __init__(self, fn, *args):
+        import threading
+
+        self._value, self._error = None, None
+
+        def run():
+            try:
+                self._value = fn(*args)
+            except BaseException as exc:  # noqa: BLE001  (handed to the caller's thread)
+                self._error = exc
+
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+        return self._value
+
+
 def sample_columns(seed: int, n: int, k: int):
     """``numpy.random.RandomState(seed).choice(n, k, replace=False)`` — the column indices pandas' ``DataFrame.sample(n=k,
     axis=1, random_state=seed)`` picks (simulation.py:1063-1078) — or None (error logged) where NumPy raises, as the
@@ -448,7 +472,10 @@ class RetirementMonteCarloSimulator:
         # The 5 sampled columns are the ones trajectory_df.sample(n=5, axis=1, random_state=main_seed) picks (:1063-1078):
         # pandas draws them with RandomState(seed).choice(n, 5, replace=False), which permutes all n indices — 7 ms at 1e6
         # paths, as long as the kernel itself.  It is host-only work: done HERE, while the (asynchronous) launch runs.
-        picked = self._sample_columns(n)
+        # (at 10^7 paths the draw is 30-50 ms of sequential host work — as long as the path kernel: it runs on a host thread of
+        #  its own (the library call releases the GIL) and is joined where the sampled columns are gathered)
+        sampler = _BackgroundCall(self._sample_columns, n) if n >= 200_000 else None
+        picked = None if sampler else self._sample_columns(n)
         # Device -> host of the per-path summary (56 B / path) on the copy stream, behind the path kernel only; the band
         # selection (K3) is enqueued on the main stream right after and runs while the summary crosses the host link; the
         # frame is built last (the reference builds it first, simulation.py:1012-1027: same values, another order of work)
@@ -463,6 +490,8 @@ class RetirementMonteCarloSimulator:
 
         sample_trajectories_list: Optional[List[List[float]]] = None
         sample_real_trajectories_list: Optional[List[List[float]]] = None
+        if sampler:
+            picked = sampler.result()
         if picked is not None:
             sample_trajectories_list = _gather_columns(batch.trajectory, picked).tolist()
             sample_real_trajectories_list = _gather_columns(batch.real_trajectory, picked).tolist()
@@ -506,7 +535,7 @@ class RetirementMonteCarloSimulator:
         batch = E.DeviceBatch(self._current_params(), wm, max(count, 1), want="full", device=dev)
         if count > 0:
             batch.launch(self._batch_rng(n), self._stream_id, begin, count)
-        picked = self._sample_columns(n)          # (host work under the asynchronous launch; identical on every rank)
+        sampler = _BackgroundCall(self._sample_columns, n)   # (host work on a thread of its own; identical on every rank)
         comm = D._comm_device()
         # ---- per-path summary: pack [7, per] (six doubles + the flag), all-gather, trim ----
         fields = list(_FIELD_OF.values())
@@ -546,6 +575,7 @@ class RetirementMonteCarloSimulator:
         wr_observation_counts = [int(v) for v in wr_counts.tolist()]
         # ---- the 5 sampled paths: owner ranks fill their columns, the rest stays 0, sum-reduce ----
         samples = real_samples = None
+        picked = sampler.result()
         if picked is not None:    # (None on every rank or on none: same seed, same n — the collective below cannot be skipped by one rank)
             T = batch.sizes.trajectory_len
             buf = torch.zeros((2, len(picked), T), dtype=torch.float64, device=batch.trajectory.device)
