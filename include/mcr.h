@@ -316,6 +316,13 @@ int mcr_draw_shocks_host(uint64_t seed, uint32_t stream_id, uint64_t path_begin,
 #define MCR_HELPER_MATH_EXP_PATH 15     /* in[1]=(x)            out[1]=exp(x), r^2/24 -> a^2/40 (|err| <= 3.5e-15, mean 0) */
 #define MCR_HELPER_MATH_NEG2LOG_PATH 16 /* in[1]=(x as uint32)  out[1]=-2 ln((x+0.5) 2^-32), series to r^4 (<= 3.6e-13 absolute) */
 #define MCR_HELPER_MATH_SINCOS_PATH 17  /* in[1]=(x as uint32)  out[2]=(sin, cos), cos series to dl^4 (<= 4.7e-15 absolute)  */
+/* The month as the path kernel RUNS it since ABI v7 (csrc/mcr_device.h, "TOLERANCE FORM of the month"): the reference's
+ * formulas in closed form — both assets sell the fraction target / capacity of their balance, the rebalance is one quotient —
+ * with fused multiply-adds and uncorrected reciprocals: equal to the reference's arithmetic up to roundings (~1e-16 relative per
+ * operation) while both effective realized-gains rates are <= 1 - 1e-6; parameter blocks with a higher rate run the exact path
+ * forms above (the reference's denominator clamps, simulation.py:227,:307-310, can bind there), and so do these two helpers. */
+#define MCR_HELPER_WITHDRAW_MONTH 18   /* :726-790  in[5]=(b1,cb1,b2,cb2,need) out[6]=(b1,cb1,b2,cb2,gross withdrawn,net cash) */
+#define MCR_HELPER_REBALANCE_MONTH 19  /* :274-359  in[4]=(b1,cb1,b2,cb2) out[4] */
 /* Evaluates helper `which` ON THE DEVICE for n rows (host buffers, row-major). */
 int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, double* out,
                          int64_t n, int device);

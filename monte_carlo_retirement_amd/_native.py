@@ -44,6 +44,8 @@ MCR_HELPER_ANNUAL_TAX_PATH = 14
 MCR_HELPER_MATH_EXP_PATH = 15
 MCR_HELPER_MATH_NEG2LOG_PATH = 16
 MCR_HELPER_MATH_SINCOS_PATH = 17
+MCR_HELPER_WITHDRAW_MONTH = 18
+MCR_HELPER_REBALANCE_MONTH = 19
 _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_WITHDRAW: (5, 4),
     MCR_HELPER_NLV: (4, 1),
@@ -63,6 +65,8 @@ _HELPER_ARITY = {  # which -> (n_in, n_out)
     MCR_HELPER_MATH_EXP_PATH: (1, 1),
     MCR_HELPER_MATH_NEG2LOG_PATH: (1, 1),
     MCR_HELPER_MATH_SINCOS_PATH: (1, 2),
+    MCR_HELPER_WITHDRAW_MONTH: (5, 6),
+    MCR_HELPER_REBALANCE_MONTH: (4, 4),
 }
 
 

@@ -537,8 +537,8 @@ __device__ __forceinline__ void rebalance_path(const LaneParams& P, double& b1, 
 // arithmetic up to roundings (DevParams::exact_month = 0, derive_params).  Configurations with a rate above that (a 100 % tax
 // on realized gains) run the exact forms in the generic kernel variants.  One sub-case is resolved differently: alive, total
 // balance > 1e-6 but total liquidation value <= 1e-6 (needs a balance below 1e-6 / (1 - r) dollars in the very month the path
-// fails): the reference sells target x weight from each asset (:750-755), the closed form sells nothing — at most
-// 1e-6 / (1 - r) dollars in the failing year's residual sample.
+// fails): the reference then splits the target by the allocation weights instead of the capacity shares (:750-755), the closed
+// form keeps the capacity shares — the two differ by at most 1e-6 / (1 - r) dollars in the failing year's residual sample.
 // Every other difference is a relative perturbation of ~1e-16 per operation — what a rounding is; measured against the oracle
 // (profiles/r04/k1_accuracy_*.txt): worst path-level error relative to the path's money scale, flips of Success flags.
 

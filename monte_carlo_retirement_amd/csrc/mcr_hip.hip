@@ -424,7 +424,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                     const double target = fmin(need, cap);                            // :739-742
                     if (need > kEps && target < need - kEps) yfail = true;            // :743-748 (FAIL-3) = :784-790 (FAIL-4): the net cash is the target
                     double phi = target * recip_nr<false>(cap);                       // :750-765
-                    if (!(cap > kEps)) { MCR_MASKED_MOVE; phi = 0.0; }
+                    if (!(cap > 0.0)) { MCR_MASKED_MOVE; phi = 0.0; }                 // (0 < cap <= 1e-6: still the capacity shares, see mcr_device.h)
                     if (kSummary) {
                         const double gross = phi * (b1 + b2);                         // :766, :777: gross withdrawals of the month
                         tg1 += gross;
@@ -674,6 +674,45 @@ __global__ void helper_kernel(int which, const DevParams P, const double* in, do
 #undef MCR_ATAX
             out[5 * i + 0] = b1; out[5 * i + 1] = c1; out[5 * i + 2] = b2; out[5 * i + 3] = c2;
             out[5 * i + 4] = tf ? 1.0 : 0.0;
+            break;
+        }
+        case MCR_HELPER_WITHDRAW_MONTH: {   // the month's withdrawal as the path kernel runs it for this parameter block
+            const double* x = in + 5 * i;
+            double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
+            const double need = x[4];
+            double gross, net;
+            if (P.exact_month) {            // (:726-790 in the exact path forms, as in path_kernel<..., EXACT = true>)
+                const LaneParams L = lane_params(P);
+                double cap1, cap2, g1, n1, g2, n2;
+                net_liquidation_values2<true, true>(b1, c1, L.real_rate1, b2, c2, L.real_rate2, cap1, cap2);
+                const double cap = cap1 + cap2, target = fmin(need, cap);
+                double prop1 = fdiv<false>(cap1, cap);
+                if (!(cap > kEps)) prop1 = P.alloc1;
+                withdraw2<true, true>(b1, c1, target * prop1, L.real_rate1, g1, n1, b2, c2, target * (1.0 - prop1), L.real_rate2, g2, n2);
+                gross = g1 + g2; net = n1 + n2;
+            } else {                        // the closed form (mcr_device.h: TOLERANCE FORM of the month)
+                const LaneParams L = lane_params_tol(P);
+                const double cap = P.tax_mask == 3 ? capacity_tol<true, true>(b1, c1, L.real_rate1, b2, c2, L.real_rate2)
+                                 : P.tax_mask == 2 ? capacity_tol<false, true>(b1, c1, L.real_rate1, b2, c2, L.real_rate2)
+                                 : P.tax_mask == 1 ? capacity_tol<true, false>(b1, c1, L.real_rate1, b2, c2, L.real_rate2)
+                                                   : capacity_tol<false, false>(b1, c1, L.real_rate1, b2, c2, L.real_rate2);
+                const double target = fmin(need, cap);
+                double phi = target * recip_nr<false>(cap);
+                if (!(cap > 0.0)) phi = 0.0;
+                gross = phi * (b1 + b2); net = target;
+                sell_fraction_tol<true>(phi, b1, c1, b2, c2);
+            }
+            double* o = out + 6 * i;
+            o[0] = b1; o[1] = c1; o[2] = b2; o[3] = c2; o[4] = gross; o[5] = net;
+            break;
+        }
+        case MCR_HELPER_REBALANCE_MONTH: {  // the month's rebalance as the path kernel runs it for this parameter block
+            const double* x = in + 4 * i;
+            double b1 = x[0], c1 = x[1], b2 = x[2], c2 = x[3];
+            if (P.exact_month) rebalance_path<true>(lane_params(P), b1, c1, b2, c2);
+            else if (P.any_real_rate) rebalance_tol<true>(P, lane_params_tol(P), b1, c1, b2, c2);
+            else rebalance_tol<false>(P, lane_params_tol(P), b1, c1, b2, c2);
+            out[4 * i + 0] = b1; out[4 * i + 1] = c1; out[4 * i + 2] = b2; out[4 * i + 3] = c2;
             break;
         }
         case MCR_HELPER_MATH_NEG2LOG: out[i] = neg2_log_u32((uint32_t)in[i], tab, MathRegs::literals()); break;
@@ -1763,6 +1802,8 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
         case MCR_HELPER_MATH_EXP_PATH: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_NEG2LOG_PATH: n_in = 1; n_out = 1; break;
         case MCR_HELPER_MATH_SINCOS_PATH: n_in = 1; n_out = 2; break;
+        case MCR_HELPER_WITHDRAW_MONTH: n_in = 5; n_out = 6; break;
+        case MCR_HELPER_REBALANCE_MONTH: n_in = 4; n_out = 4; break;
         default: set_error("unknown helper %d", which); return MCR_ERR_INVALID_ARG;
     }
     if (!in || !out || n < 0) { set_error("bad arguments"); return MCR_ERR_INVALID_ARG; }
@@ -1770,7 +1811,8 @@ int mcr_eval_helper_host(int which, const mcr_params* p, const double* in, doubl
     DevParams d;
     std::memset(&d, 0, sizeof(d));
     if (which == MCR_HELPER_REBALANCE || which == MCR_HELPER_ANNUAL_TAX || which == MCR_HELPER_WITHDRAW2_PATH ||
-        which == MCR_HELPER_NLV2_PATH || which == MCR_HELPER_REBALANCE_PATH || which == MCR_HELPER_ANNUAL_TAX_PATH) {
+        which == MCR_HELPER_NLV2_PATH || which == MCR_HELPER_REBALANCE_PATH || which == MCR_HELPER_ANNUAL_TAX_PATH ||
+        which == MCR_HELPER_WITHDRAW_MONTH || which == MCR_HELPER_REBALANCE_MONTH) {
         if (!p) { set_error("helper %d needs params", which); return MCR_ERR_INVALID_ARG; }
         rc = derive_params(p, 0, &d);
         if (rc != MCR_OK) return rc;

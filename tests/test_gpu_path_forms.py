@@ -92,3 +92,54 @@ def test_path_forms_are_bit_identical_to_the_reference_arithmetic(oracle, seed):
         got = E.eval_helper_host(N.MCR_HELPER_ANNUAL_TAX_PATH, p, np.column_stack((b1, c1, b2, c2, g1, g2)))
         exp = np.array([[*o[:4], 1.0 if o[4] else 0.0] for o in (oracle.annual_tax(p, b1[i], c1[i], b2[i], c2[i], g1[i], g2[i]) for i in range(n))])
         _same(got.ravel(), exp.ravel(), ("annual_tax", cfg))
+
+
+def _close(got, exp, scale, what, rel=2e-14, abs_tol=4e-6):
+    """|got - exp| <= rel x the state's money scale (a few hundred roundings' worth), or <= abs_tol for the DUST states this
+    test feeds on purpose (balances of 0 .. 3e-6 dollars around the reference's 1e-6 threshold, `_money`): with a total
+    liquidation value below 1e-6 the reference splits the target by allocation weight instead of capacity share
+    (simulation.py:750-755), so whether such a balance is sold out or kept differs — by the balance itself."""
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    err = np.abs(got - exp)
+    ok = (err <= abs_tol) | (err <= rel * scale)
+    bad = np.nonzero(~ok)[0]
+    assert bad.size == 0, (what, bad[:5].tolist(), got[bad[:5]].tolist(), exp[bad[:5]].tolist(), scale[bad[:5]].tolist())
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_month_forms_the_kernel_runs_match_the_reference_arithmetic(oracle, seed):
+    """The month AS THE PATH KERNEL RUNS IT (MCR_HELPER_WITHDRAW_MONTH / MCR_HELPER_REBALANCE_MONTH: the closed form of
+    csrc/mcr_device.h — both assets sell target / capacity, one-quotient rebalance, FMAs, uncorrected reciprocals; the exact path
+    forms for parameter blocks with a realized-gains rate above 1 - 1e-6) against the oracle's restatement of the reference's
+    sequence (simulation.py:726-796: two liquidation values, the proportional split, two withdrawals; then the rebalance) on
+    random reachable states: within 2e-14 of the state's money scale, or within the reference's own 1e-6 dust threshold."""
+    rng = np.random.default_rng(seed)
+    n = 4000
+    kinds = set()
+    for _ in range(16):
+        cfg, p = _params(rng)
+        use1, r1 = cfg["inv1_use_realized_gains_tax_system"], cfg["inv1_realized_gains_tax_rate"]
+        use2, r2 = cfg["inv2_use_realized_gains_tax_system"], cfg["inv2_realized_gains_tax_rate"]
+        a1 = cfg["allocation_inv1_pct"]
+        kinds.add(bool((use1 and r1 > 1 - 1e-6) or (use2 and r2 > 1 - 1e-6)))
+        b1, c1, b2, c2 = _states(rng, n)
+        total = b1 + b2
+        need = np.where(rng.integers(0, 6, n) == 0, 0.0, total * rng.uniform(0, 1.3, n) + rng.uniform(0, 3e-6, n))
+        got = E.eval_helper_host(N.MCR_HELPER_WITHDRAW_MONTH, p, np.column_stack((b1, c1, b2, c2, need)))
+        exp = np.empty((n, 6))
+        for i in range(n):
+            cap1, cap2 = oracle.nlv(b1[i], c1[i], use1, r1), oracle.nlv(b2[i], c2[i], use2, r2)
+            cap = cap1 + cap2
+            target = max(0.0, min(need[i], cap))
+            prop1 = cap1 / cap if cap > 1e-6 else a1
+            w1 = oracle.withdraw(b1[i], c1[i], target * prop1, use1, r1)
+            w2 = oracle.withdraw(b2[i], c2[i], target * (1.0 - prop1), use2, r2)
+            exp[i] = (w1[0], w1[1], w2[0], w2[1], w1[2] + w2[2], w1[3] + w2[3])
+        scale = np.maximum(np.maximum(total, c1 + c2), 1.0)
+        for k, name in enumerate(("b1", "c1", "b2", "c2", "gross", "net")):
+            _close(got[:, k], exp[:, k], scale, ("withdraw month", name, cfg))
+        got = E.eval_helper_host(N.MCR_HELPER_REBALANCE_MONTH, p, np.column_stack((b1, c1, b2, c2)))
+        exp = np.array([oracle.rebalance(p, b1[i], c1[i], b2[i], c2[i]) for i in range(n)])
+        for k, name in enumerate(("b1", "c1", "b2", "c2")):
+            _close(got[:, k], exp[:, k], scale, ("rebalance month", name, cfg))
+    assert kinds == {True, False}        # both the closed form and the exact-month parameter blocks were exercised
