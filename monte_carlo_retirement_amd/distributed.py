@@ -113,6 +113,41 @@ def all_reduce_sum_(tensor) -> None:
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
 
 
+def probe_candidates(months, n_paths: int, shard_min_paths: int, probe):
+    """Success counters of several candidate working-month counts over the path range ``[0, n_paths)`` under a process
+    group: ``probe(path_begin, count, months) -> int64 [len(months), 2]`` (``{successes, paths}`` per month; a numpy array or a
+    torch tensor on any device) runs the local kernels.  Batches of at least ``shard_min_paths`` are sharded by PATH RANGE
+    (every rank counts all candidates on its shard); smaller ones are split by CANDIDATE (rank r takes ``months[r::world]`` over
+    the whole range — with fewer candidates than ranks the others contribute zeros).  Either way the per-candidate counter
+    block is summed with ONE all-reduce and every rank returns the same numpy array ``[len(months), 2]``.  Without a process
+    group: ``probe(0, n_paths, months)``."""
+    import torch
+
+    months = [int(m) for m in months]
+    n = int(n_paths)
+
+    def as_tensor(x, device):
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.int64))
+        return t.to(device=device, dtype=torch.int64).reshape(-1, 2)
+
+    if not is_active():
+        return as_tensor(probe(0, n, months), torch.device("cpu")).numpy()
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    counts = torch.zeros((len(months), 2), dtype=torch.int64, device=_comm_device())
+    if n >= int(shard_min_paths):
+        begin, count = shard_range(n, rank, world)
+        if count > 0:
+            counts.copy_(as_tensor(probe(begin, count, months), counts.device))
+    else:
+        mine = list(range(rank, len(months), world))
+        if mine:
+            counts[mine] = as_tensor(probe(0, n, [months[i] for i in mine]), counts.device)
+    all_reduce_sum_(counts)
+    return counts.cpu().numpy()
+
+
 def all_reduce_minmax_(minmax) -> None:
     """In-place: ``minmax[0]`` = min over ranks, ``minmax[1]`` = max over ranks (histogram range)."""
     import torch.distributed as dist

@@ -608,34 +608,15 @@ class RetirementMonteCarloSimulator:
         rank counts all candidates on its shard); smaller ones are split by CANDIDATE (rank r takes
         ``months[r::world]`` over the whole range).  Either way the counter block is summed with one
         all-reduce and every rank sees the same probabilities (and replays the same search)."""
-        import torch
-
         months = [int(m) for m in months]
         n = int(num_simulations)
         params, rng, dev = self._current_params(), self._batch_rng(n), self._local_device()
-        if not D.is_active():
-            counts = E.probe_months(params, rng, self._stream_id, 0, n, months, device=dev)
-        else:
-            import torch.distributed as dist
 
-            rank, world = dist.get_rank(), dist.get_world_size()
-            if n >= self.shard_min_paths:
-                begin, count = D.shard_range(n, rank, world)
-                counts = E.probe_months(params, rng, self._stream_id, begin, count, months, device=dev)
-                if count == 0:
-                    counts.zero_()
-            else:
-                counts = torch.zeros((len(months), N.MCR_N_COUNTERS), dtype=torch.int64,
-                                     device=torch.device("cuda", dev))
-                mine = list(range(rank, len(months), world))
-                if mine:
-                    counts[mine] = E.probe_months(params, rng, self._stream_id, 0, n,
-                                                  [months[i] for i in mine], device=dev)
-            if dist.get_backend() != "nccl":
-                counts = counts.cpu()
-            D.all_reduce_sum_(counts)
-        ok = counts[:, N.MCR_CTR_SUCCESS].cpu().numpy()
-        return {m: float(np.float64(int(ok[i])) / np.float64(n) * 100.0) for i, m in enumerate(months)}
+        def probe(path_begin, count, ms):
+            return E.probe_months(params, rng, self._stream_id, path_begin, count, ms, device=dev)
+
+        counts = D.probe_candidates(months, n, self.shard_min_paths, probe)
+        return {m: float(np.float64(int(counts[i, N.MCR_CTR_SUCCESS])) / np.float64(n) * 100.0) for i, m in enumerate(months)}
 
     def _probe_success_probability(self, working_months: int, num_simulations: int) -> float:
         """Success % of one batch from the count-only kernel (no per-path HBM traffic)."""

@@ -61,10 +61,24 @@ def main():
         t.start(); t.join()
     seen["after"] = D.is_active()
     seen["broadcast_after"] = D.broadcast_int(1000 + rank)               # rank 0's value everywhere again
+    # the search's probes under a group (distributed.probe_candidates, what RetirementMonteCarloSimulator._probe_many runs):
+    # small batches split by CANDIDATE month over the ranks (fewer candidates than ranks: the rest contribute zeros), large
+    # ones by path range; the local "kernel" is the oracle here
+    evaluated = []
+
+    def oracle_probe(begin, count, months):
+        evaluated.append((int(begin), int(count), [int(m) for m in months]))
+        return np.array([[int(O.run_batch(params, 777, 0, begin, count, m, want_summary=False, want_trajectories=False)["counters"][0]), count]
+                         for m in months], dtype=np.int64)
+
+    probe_few = D.probe_candidates([20, 21, 22], 64, 10**6, oracle_probe).tolist()                 # 3 candidates: ranks 3.. idle
+    probe_many = D.probe_candidates(list(range(10, 27)), 48, 10**6, oracle_probe).tolist()         # 17 candidates (the bench's search)
+    probe_range = D.probe_candidates([20, 25], n_total, 50, oracle_probe).tolist()                 # by path range, ragged tail
     with open(f"{out_path}.{rank}", "w") as fh:
         json.dump({"main_seed": unseeded.main_seed, "own_seed": own.main_seed, "rank": rank, "world": world, "shards": shards, "success": red.success, "paths": red.paths,
                    "wr": red.wr_obs_counts.tolist(), "ruin": red.ruin_year_bins.tolist(),
-                   "prob": red.success_probability_pct, "minmax": mm.tolist(), "active": D.is_active(), "local_only": seen}, fh)
+                   "prob": red.success_probability_pct, "minmax": mm.tolist(), "active": D.is_active(), "local_only": seen,
+                   "probe_few": probe_few, "probe_many": probe_many, "probe_range": probe_range, "probe_calls": evaluated}, fh)
     dist.barrier()
     dist.destroy_process_group()
 

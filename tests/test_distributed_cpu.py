@@ -45,8 +45,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 301), (3, 64)])
+@pytest.mark.parametrize("world,n_total", [(2, 301), (3, 64), (8, 1003)])
 def test_sharded_counts_equal_single_process(tmp_path, oracle, world, n_total):
+    """(8 ranks = the world size the driver's scaling run uses: ragged shards 126 x 7 + 121, candidates split 8 ways.)"""
     wm = 30
     out = str(tmp_path / "res")
     port = _free_port()
@@ -75,3 +76,21 @@ def test_sharded_counts_equal_single_process(tmp_path, oracle, world, n_total):
         lo = r["local_only"]
         assert (lo["inside"], lo["nested"], lo["after_nested"], lo["other_thread"], lo["after"]) == (False, False, False, True, True), lo
         assert lo["broadcast_inside"] == 1000 + r["rank"] and lo["broadcast_after"] == 1000
+    # the search's probes: every rank ends with the single-process counts, whatever the split
+    p = params_from_config(cfg)
+
+    def single(months, n):
+        return [[int(oracle.run_batch(p, 777, 0, 0, n, m, want_summary=False, want_trajectories=False)["counters"][0]), n] for m in months]
+
+    few, many, ranged = single([20, 21, 22], 64), single(list(range(10, 27)), 48), single([20, 25], n_total)
+    for r in res:
+        assert r["probe_few"] == few and r["probe_many"] == many and r["probe_range"] == ranged, r["rank"]
+        calls = r["probe_calls"]
+        # by candidate: rank r evaluates months[r::world] over the WHOLE range, or nothing at all
+        mine_few, mine_many = [20, 21, 22][r["rank"]::world], list(range(10, 27))[r["rank"]::world]
+        expected = ([[0, 64, mine_few]] if mine_few else []) + ([[0, 48, mine_many]] if mine_many else [])
+        begin, count = D.shard_range(n_total, r["rank"], world)
+        expected += [[begin, count, [20, 25]]] if count else []
+        assert calls == expected, (r["rank"], calls, expected)
+    if world == 8:
+        assert sum(1 for r in res if not [20, 21, 22][r["rank"]::world]) == 5      # five ranks sat the 3-candidate round out
