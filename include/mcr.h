@@ -198,10 +198,12 @@ int mcr_validate_params(const mcr_params* p);
  * RandomState(seed).permutation(n): MT19937 seeded with init_genrand(seed), a Fisher-Yates shuffle from the top with
  * masked-rejection bounded draws.  NumPy shuffles an n-element array to get them (7 ms at n = 1e6, 0.7 s at 1e8 — as
  * long as the path kernel takes for n paths); this restatement only generates the n - 1 draws and traces the k wanted
- * positions back through the swaps: the same indices, bit for bit (tests/test_abi_cpu.py), at about half the time, so the
- * draw hides under the asynchronous kernel launch at every n.  Host-only (no device needed).  out: HOST int64[k].
+ * positions back through the swaps (branch-free rejection, the tracked positions in one vector register): the same
+ * indices, bit for bit (tests/test_abi_cpu.py), in a fifth of NumPy's time.  Host-only (no device needed).  out: HOST int64[k].
  * Needs 1 <= k <= 64, k <= n, n <= 2^32; seed is the 32-bit seed (RandomState rejects larger ones).  Allocates 4 n bytes
- * of scratch on the host for the call. */
+ * of scratch on the host for the call and takes ~4 ns per path of sequential host time (MT19937 cannot be split): 40 ms and
+ * 40 MB at 10^7 paths, 0.4 s and 400 MB at 10^8 — above 5 x 10^7 paths the call says so once on stderr.  Callers hide it on
+ * a host thread next to the asynchronous kernel launch (the drop-in class does). */
 int mcr_sample_columns(uint32_t seed, uint64_t n, int32_t k, int64_t* out);
 /* stream_payment_start_month_index (simulation.py:47-63). */
 int32_t mcr_stream_start_month_index(double current_age, int32_t working_months, double start_at_age);
@@ -275,7 +277,8 @@ int mcr_run_batch_multi_host_rng(const mcr_params* p, const mcr_rng* rng, uint32
  * accumulation months do not depend on the candidate under common random numbers (simulation.py:513-579), so ONE sweep
  * runs them to the largest candidate and stores the state at the end of every candidate month, and ONE launch
  * (grid.y = candidate) resumes every decumulation from its snapshot; the snapshots are a stream-ordered allocation
- * (80 B per path and candidate).  Otherwise: one count-only launch per candidate, forked onto internal HIP streams
+ * (80 B per path and candidate; requests that would need more than 4 GiB of them, stream lists beyond the by-value block and
+ * parameter blocks that need the exact month take the route below).  Otherwise: one count-only launch per candidate, forked onto internal HIP streams
  * so the candidates share the GPU concurrently, joined back onto `hip_stream`.  Asynchronous like mcr_run_batch.
  * counts: DEVICE uint64 [n_candidates][MCR_N_COUNTERS] = {successes, paths} per candidate (zeroed by
  * the call).  Common random numbers across candidates hold as in the reference (same path range, same

@@ -1867,7 +1867,9 @@ int mcr_row_quantiles(const double* rows, int64_t row_stride, int32_t n_rows, in
     int collect_per_row = n >= ((int64_t)1 << 23) ? 4 : (n >= ((int64_t)1 << 21) ? 4 : 2);   // a few MB of candidates per row
     if (const char* e = std::getenv("MCR_RQ_COLLECT_PER_ROW")) { const int t = std::atoi(e); if (t > 0) collect_per_row = t; }
     const size_t hrow = (size_t)kRqMaxQ * kRqMaxSubBins;
-    // The six stages for rows [r0, r0 + nr) on stream `st` (every per-row array shifted to the group's first row).
+    // The six stages for rows [r0, r0 + nr) on stream `st` (every per-row array shifted to the group's first row).  Every caller
+    // passes the whole call (r0 = 0, nr = n_rows) since round 3 measured the row-group pipelining and dropped it (below); the
+    // row-range form of the stages is kept because it costs nothing and documents what a stage depends on.
     auto head = [&](hipStream_t st, int r0, int nr, unsigned int* fb_reset) {
         const double* rg = rows + (int64_t)r0 * row_stride;
         // (1) coarse brackets from the first kRqTiny entries of every row, sorted in LDS (paths are exchangeable; an

@@ -851,8 +851,8 @@ hipError_t host_ctx_reserve(HostCtx* c, size_t bytes) {
 // Fork/join streams (mcr_host.h: StreamFork): a few non-blocking side streams + events, leased from a process-wide pool
 // keyed by device for the duration of ONE call's enqueue (like HostCtx).  A lease only has to cover the host-side
 // enqueue: the side streams are in-order, and a stream that waits on an event waits for the record that preceded the
-// wait call, so the next lessee's records cannot disturb work that is still running.  Users: mcr_probe_months_rng
-// (candidates forked onto side streams) and mcr_row_quantiles (row groups pipelined against each other).
+// wait call, so the next lessee's records cannot disturb work that is still running.  User: mcr_probe_months_rng
+// (candidates forked onto side streams; mcr_row_quantiles' row-group pipelining was measured and dropped in round 3).
 static std::vector<StreamFork*> g_idle_fork;   // guarded by g_pool_mu
 constexpr int kStreamForkIdlePerDevice = 2;
 
@@ -1186,6 +1186,10 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
     // kernel variant: output mode x RNG x (any effective realized-gains rate?) x (any annual-gains tax?); injected
     // shocks (parity hook) always take the full-output variant, whose every store is null-checked
     bool split = !injected && !np_rng && mode == 0 && (uint64_t)grid.x * (kBlock / 64) <= split_max_waves();
+    // The producer / consumer form counts on both halves of a workgroup executing the same number of barriers: producers run
+    // rows [0, total_months), consumers wm accumulation months + 12 months per retirement year.  (It also counts on gfx9's
+    // s_barrier not waiting for waves that have ended — producers return while consumers still reduce their counts.)
+    if (split && d.total_months != d.working_months + kMPY * d.retirement_years) { set_error("internal: total_months != working_months + 12 retirement_years"); return MCR_ERR_INVALID_ARG; }
     size_t lds = 0;
     rc = plan_path_kernel_lds(d, mode, np_rng, injected != nullptr, split, io.out.hist_n_bins, &lds);
     if (rc != MCR_OK) return rc;
@@ -1346,6 +1350,7 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
     if (e == hipSuccess) {
         const dim3 block(kBlock), g1((unsigned)((n_paths + kBlock - 1) / kBlock)), g2(g1.x, (unsigned)n_cand);
         // (either phase takes the producer / consumer split on its own while its launch leaves SIMDs idle)
+        if (top.total_months != top.working_months + kMPY * top.retirement_years) { (void)hipFreeAsync(mem, stream); set_error("internal: total_months != working_months + 12 retirement_years"); return MCR_ERR_INVALID_ARG; }   // (the split forms' barrier counts, see launch_paths)
         const bool split1 = (uint64_t)g1.x * (kBlock / 64) <= split_max_waves();
         const bool split2 = (uint64_t)g2.x * g2.y * (kBlock / 64) <= split_max_waves();
         const dim3 block2(2 * kBlock);
