@@ -173,7 +173,7 @@ def aux_hbm_kernels(torch, n, rho=0.3, allocations=3):
     ms_k1 = timed(lambda: b.launch(12345, 1, 0))
     bytes_k1 = n * (8 * (2 * T + ry + 6) + 1)
     # K3 depends on where the driver places the slab: the same kernels on the same data run the slab pass at 5.3 or at 6.0
-    # TB/s from one allocation of the batch to the next (tools/k3_alloc_modes.py).  Three allocations, the
+    # TB/s from one allocation of the batch to the next (DESIGN.md 5 / LABNOTES.md, tools/k3_alloc_modes.py).  Three allocations, the
     # median reported, all three listed.
     k3_by_alloc = [timed(lambda: A.band_quantiles(b, n))]
     fallback_rows = A.last_fallback_rows()

@@ -24,7 +24,7 @@
 
 // `if (c) { MCR_MASKED_MOVE; x = y; }`: the empty asm keeps the assignment a BRANCH under the exec mask (v_cmp, s_and_saveexec,
 // moves, s_or) where the compiler would if-convert it into v_cndmask pairs — a 64-bit select costs two fp64 issue slots, the
-// masked move one and often none (§5 of DESIGN.md).  MM (a template parameter in scope at every use) = false leaves the
+// masked move one and often none (LABNOTES.md, rounds 1-3 section 5).  MM (a template parameter in scope at every use) = false leaves the
 // choice to the compiler: the producer / consumer SPLIT launches are bound by each wave's dependency chain, not by issue
 // slots, and there the compare -> scalar mask -> branch -> move round trip is the slower form (lone 50 000-path probe
 // 0.84 -> 0.79 ms, measured).  Same values either way.

@@ -66,12 +66,12 @@ __device__ __forceinline__ unsigned long long f64_bits(double x) { return (unsig
 __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) { *reinterpret_cast<unsigned long long*>(p) = bits; }
 
 // Resident waves per SIMD are worth more than a few spilled registers: the trimmed count-only kernel loses 4.4 % on
-// large batches at 4 instead of 6 workgroups per CU (measured with a larger LDS footprint), and the Philox
+// large batches at 4 instead of 6 workgroups per CU (measured with a larger LDS footprint, LABNOTES.md rounds 1-3 section 9), and the Philox
 // variants with per-path outputs gain 4.5 % (summary) / 3 % (trajectories) at 5 waves (<= 96 VGPRs, 4-10 of them
 // spilled) over 4 (up to 128); at 6 the summary variant spills too much and gives that back.  The NumPy-stream and
 // injection variants keep 4 (they need 107-128).  The count-only Philox
 // variants are held to 6 waves per SIMD (<= 80 VGPRs): the BASELINE workload of 1e6 paths is 15.26 waves per SIMD, and
-// with 5 resident waves that is 5 + 5 + 5 + a lone fourth round (+9 %); the annual-tax variant sat at 81.
+// with 5 resident waves that is 5 + 5 + 5 + a lone fourth round (+9 %, LABNOTES.md rounds 1-3 section 5); the annual-tax variant sat at 81.
 // INJ = true: shocks come from io.injected (the parity hook) instead of the RNG; only instantiated with MODE 2
 // (every output is null-checked), so the hot variants carry neither the injection branches nor their registers.
 // PHASE 0: the whole path.  PHASE 1 / 2 split it at retirement for the search (simulation.py:1180-1194 re-simulates the

@@ -127,7 +127,7 @@ def _gather_columns(rows, picked) -> np.ndarray:
     64-bit offset is folded into the view's data pointer on the host) and the stack kernel then indexes k tensors of
     T elements each.  No torch INDEXING kernel (``index_select`` / advanced indexing) ever sees the [2T+ry, stride]
     slab, which exceeds 2**32 elements from ~3.2e7 paths on: the one GPU-side abort of round 1 was such a gather
-    on a 3.3e7-path slab."""
+    on a 3.3e7-path slab (LABNOTES.md, rounds 1-3 section 11)."""
     import torch
 
     return torch.stack([rows[:, int(g)] for g in picked]).cpu().numpy()

@@ -279,7 +279,7 @@ def test_very_large_batches_use_64bit_addressing(oracle):
     del b
     torch.cuda.empty_cache()
     # the drop-in class on the same > 2^32-element slab: per-path frame, bands, sampled columns — no torch
-    # indexing kernel sees the slab
+    # indexing kernel sees the slab (LABNOTES.md, rounds 1-3 section 11)
     from monte_carlo_retirement_amd.simulation import RetirementMonteCarloSimulator
 
     sim = RetirementMonteCarloSimulator(Config(**cfgd), main_seed_override=31337)
