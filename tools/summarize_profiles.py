@@ -114,8 +114,10 @@ def main(src: str, dst: str) -> None:
                                              cwd=os.path.dirname(os.path.abspath(__file__))).strip())
     except Exception:  # noqa: BLE001
         commit, dirty = None, None
-    try:
-        box = open(os.path.join(src, "box.txt")).read().split()
+    try:   # which card: the GPU's unique id (the host name of a pool box is its container runtime's)
+        import re
+        m = re.search(r"Unique ID:\s*(0x[0-9a-fA-F]+)", open(os.path.join(src, "box.txt")).read())
+        box = [("gpu " + m.group(1)) if m else None]
     except OSError:
         box = []
     shutil.copy(os.path.join(src, "kt_medians.json"), os.path.join(dst, "kernel_trace_medians.json"))
