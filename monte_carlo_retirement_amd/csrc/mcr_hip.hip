@@ -36,6 +36,7 @@ namespace mcr {
 // ---------------------------------------------------------------------------------------------
 // K1: the per-path state machine (_run_single_simulation_path, simulation.py:476-950)
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxSegments = 8;
 struct KernelIO {
     uint64_t seed;           // Philox key
     uint64_t path_begin;
@@ -54,6 +55,12 @@ struct KernelIO {
     int32_t n_snap;
     int32_t snap_months[MCR_MAX_PROBE_CANDIDATES];   // ascending
     int32_t cand_out[MCR_MAX_PROBE_CANDIDATES];      // PHASE 2: counter block of candidate c = counters + cand_out[c] * MCR_N_COUNTERS
+    // PHASE 3 (time-sliced path blocks, see path_kernel): the first seg_n_split path blocks of the launch are cut into seg_q
+    // segments at retirement-year boundaries; `snap` holds their hand-over state, seg_flags says which segments are done
+    int32_t seg_n_split, seg_n_full, seg_q;
+    int32_t seg_year[kMaxSegments + 1];              // segment k covers retirement years [seg_year[k], seg_year[k + 1]); segment 0 also the accumulation
+    unsigned int* seg_flags;                         // [seg_n_split][seg_q], zeroed before the launch
+    int32_t seg_max_polls;                           // x ~1 us: how long a successor looks for its predecessor's flag before it recomputes the block itself
 };
 constexpr int kSplitVotePairs = 16;   // SPLIT: pairs of months between two stop votes of a workgroup (a power of two)
 constexpr int kSnapFields = 10;   // b1 b2 c1 c2 gacc1 gacc2 infl contrib | pre_fail | Philox carry words
@@ -88,6 +95,16 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // halves of a month's dependency chain then run on different SIMDs of the CU.  One workgroup barrier per pair of months
 // hands a buffer over; every wave executes the same number of them (no early exit when all lanes have failed) or has
 // terminated.  The arithmetic of every path is unchanged: counts are bit-identical to SPLIT = false.
+// PHASE 3 (count-only Philox launches of a few rounds of workgroups; launch_paths): TIME-SLICED path blocks.  A launch of B
+// equal workgroups on W resident slots ends when the busiest slot has run ceil(B / W) of them: 10^6 paths are 15.26 workgroups
+// per CU-slot, so the chip idles through most of a sixteenth round (measured: 5.15 ms where 4.77 would do, LABNOTES R4.6).
+// Small work items at the END of the dispatch order fix that (longest-processing-time-first): the first S path blocks of the
+// launch are cut into Q segments at retirement-year boundaries, and the grid is ordered [segment 0 of the S blocks] [the
+// other blocks, whole] [segment 1 x S] ... [segment Q - 1 x S].  A segment ends by storing its lanes' state (balances, bases,
+// gain accumulators, price level, flags, Philox carry, lock columns) and raising a flag; its successor — dispatched at least
+// S workgroups later, i.e. after it has long finished — loads it.  A successor that does not see the flag within a bounded
+// number of polls recomputes the block from month 0 itself: no workgroup ever waits on another one to make progress.
+// The arithmetic of every path is unchanged: counts and bins are bit-identical to PHASE 0.
 // XS = true ("extended streams"): the variants that can read income-stream records beyond the by-value block from the device
 // table and keep lock slots beyond the LDS budget in the global overflow block (DevParams::extra_streams / lock_overflow:
 // other_income_streams has no length limit in the reference, config.py:99).  A compile-time variant because the headline
@@ -102,10 +119,11 @@ constexpr bool kExactMonthDefault = true;
 constexpr bool kExactMonthDefault = false;
 #endif
 template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false, bool XS = false, bool EXACT = kExactMonthDefault>
-__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && PHASE == 0) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
+__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && (PHASE == 0 || PHASE == 3)) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
     static_assert(!XS || (PHASE == 0 && !SPLIT && TAXED == 3 && ANNUAL), "extended stream lists run the generic whole-path form");
+    static_assert(PHASE != 3 || (MODE == 0 && RNG == 0 && !INJ && !SPLIT && !XS), "time-sliced blocks exist for the count-only Philox variants");
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
@@ -153,11 +171,20 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // [hist_n_bins] final-balance histogram of the workgroup (mcr_outputs.hist_bins), when requested
     const int ry = P.retirement_years;
     const int n_blk = 1 + (ry + 2) + (ry + 1);
-    const int n_hist = (PHASE == 0 && io.out.hist_bins != nullptr) ? io.out.hist_n_bins : 0;
+    const int n_hist = ((PHASE == 0 || PHASE == 3) && io.out.hist_bins != nullptr) ? io.out.hist_n_bins : 0;
     for (int k = threadIdx.x; k < n_blk + n_hist; k += kThreads) blk[k] = 0u;
     __syncthreads();
 
-    const uint64_t local = (uint64_t)blockIdx.x * kBlock + (unsigned)tid;
+    // PHASE 3: which path block and which segment of it this workgroup runs (seg < 0: a whole block)
+    int seg = -1, seg_block = 0;
+    unsigned int path_block = blockIdx.x;
+    if (PHASE == 3) {
+        const int S = io.seg_n_split, F = io.seg_n_full, bid = (int)blockIdx.x;
+        if (bid < S) { seg = 0; seg_block = bid; path_block = (unsigned)bid; }
+        else if (bid < S + F) { path_block = (unsigned)bid; }
+        else { const int k = bid - S - F; seg = 1 + k / S; seg_block = k % S; path_block = (unsigned)seg_block; }
+    }
+    const uint64_t local = (uint64_t)path_block * kBlock + (unsigned)tid;
     const bool valid = local < io.n_paths;
     const uint64_t li = valid ? local : (io.n_paths - 1);  // tail lanes shadow the last path, write nothing
     const uint64_t path = io.path_begin + li;
@@ -299,9 +326,48 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
         if (wm & 1) begin_month(wm - 1);   // the pair of rows (wm - 1, wm) was staged during the accumulation: stage it again
     }
+    // PHASE 3: a later segment of a time-sliced block takes its lanes' state over from its predecessor
+    constexpr int kSegFixedFields = 9;     // b1 b2 c1 c2 gacc1 gacc2 infl | flags | Philox carry; then the lock columns
+    auto seg_at = [&](int f) { return io.snap + ((size_t)seg_block * (size_t)(kSegFixedFields + P.n_lock_slots) + (size_t)f) * kBlock + (size_t)tid; };
+    __shared__ int seg_ok_s;
+    bool seg_resumed = false;
+    int y_begin = 0, y_end = ry;
+    unsigned long long seg_state_flags = 0ull;
+    if (PHASE == 3 && seg >= 0) {
+        y_end = io.seg_year[seg + 1];
+        if (seg > 0) {
+            if (threadIdx.x == 0) {
+                const unsigned int* f = io.seg_flags + (size_t)seg_block * (size_t)io.seg_q + (size_t)(seg - 1);
+                int ok = 0;
+                for (int spin = 0; spin < io.seg_max_polls; ++spin) {
+                    if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                seg_ok_s = ok;
+            }
+            __syncthreads();
+            seg_resumed = seg_ok_s != 0;     // (otherwise: this workgroup runs the block from month 0 itself, up to its own end)
+            if (seg_resumed) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                b1 = *seg_at(0); b2 = *seg_at(1); c1 = *seg_at(2); c2 = *seg_at(3);
+                if (ANNUAL) { gacc1 = *seg_at(4); gacc2 = *seg_at(5); }    // (otherwise identically 0 and never read)
+                infl = *seg_at(6);
+                seg_state_flags = f64_bits(*seg_at(7));
+                const unsigned long long cw = f64_bits(*seg_at(8));
+                carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
+                for (int k = 0; k < P.n_lock_slots; ++k) lock_lds[(size_t)k * kBlock + tid] = *seg_at(kSegFixedFields + k);
+                y_begin = io.seg_year[seg];
+                const int r0 = wm + kMPY * y_begin;
+                if (r0 >= prio_t3) __builtin_amdgcn_s_setprio(0);
+                else if (r0 >= prio_t2) __builtin_amdgcn_s_setprio(1);
+                else if (r0 >= prio_t1) __builtin_amdgcn_s_setprio(2);
+                if (r0 & 1) begin_month(r0 - 1);   // the pair of rows (r0 - 1, r0) was staged by the predecessor: stage it again
+            }
+        }
+    }
 
     // ---- accumulation (:513-579): no lane leaves this loop early ----
-    for (int m = 1; m <= (PHASE == 2 ? 0 : wm); ++m) {
+    for (int m = 1; m <= ((PHASE == 2 || (PHASE == 3 && seg_resumed)) ? 0 : wm); ++m) {
         if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) {  // :514-517 (wave-uniform: a scalar branch, not a select)
             asm volatile("");
             contrib *= P.contrib_growth_factor;
@@ -352,7 +418,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     int ruin_bin = pre_fail ? 0 : -1;
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
-    for (; year < ry; ++year) {
+    if (PHASE == 3 && seg_resumed) {   // flags of the hand-over state: alive | succeeded << 1 | (ruin_bin + 1) << 8 | done_years << 24
+        alive = (seg_state_flags & 1ull) != 0ull;
+        succeeded = (seg_state_flags & 2ull) != 0ull;
+        ruin_bin = (int)((seg_state_flags >> 8) & 0xFFFFull) - 1;
+        done_years = (int)(seg_state_flags >> 24);
+        year = y_begin;
+    }
+    for (; year < (PHASE == 3 ? y_end : ry); ++year) {
         if (!SPLIT && __builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
         if (SPLIT) { lane_alive = alive; if (wg_dead) break; }           // (SPLIT: the wave keeps pace with its producers' barriers until the workgroup votes to stop)
         double tg1 = 0.0, tg2 = 0.0, treal = 0.0;  // :635-637
@@ -495,6 +568,20 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         put_sample(t_idx++, 0.0, infl);
         if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], kNanBits);
     }
+    if (PHASE == 3 && seg >= 0 && seg < io.seg_q - 1) {
+        // not the block's last segment: hand the lanes' state over and raise the flag (every wave gets here: no early return above)
+        *seg_at(0) = b1; *seg_at(1) = b2; *seg_at(2) = c1; *seg_at(3) = c2;
+        if (ANNUAL) { *seg_at(4) = gacc1; *seg_at(5) = gacc2; }
+        *seg_at(6) = infl;
+        store_bits(seg_at(7), (alive ? 1ull : 0ull) | (succeeded ? 2ull : 0ull) | ((unsigned long long)(ruin_bin + 1) << 8) | ((unsigned long long)done_years << 24));
+        store_bits(seg_at(8), ((unsigned long long)carry.w3 << 32) | (unsigned long long)carry.w2);
+        for (int k = 0; k < P.n_lock_slots; ++k) *seg_at(kSegFixedFields + k) = lock_lds[(size_t)k * kBlock + tid];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(io.seg_flags + (size_t)seg_block * (size_t)io.seg_q + (size_t)seg, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 
     // ---- terminal partial tax period (:873-898) ----
     if (P.total_months % kMPY != 0) {  // wave-uniform
@@ -539,7 +626,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     // "Final Balance" of the successful cohort on the caller's bin edges (plotting.py:44-59; np.histogram(x, bins=edges):
     // bin k = [e_k, e_k+1), the last one closed, values outside the edges dropped).  Once per path, after 10^2..10^3
     // months of arithmetic: a per-lane binary search straight over the (L2-resident) edge array costs nothing measurable.
-    if (PHASE == 0 && n_hist > 0 && valid && succeeded) {
+    if ((PHASE == 0 || PHASE == 3) && n_hist > 0 && valid && succeeded) {
         const double* __restrict__ e = io.out.hist_edges;
         if (final_balance >= e[0] && final_balance <= e[n_hist]) {
             int lo = 0, hi = n_hist;             // e[lo] <= x and (hi == n_hist or x < e[hi])
@@ -554,7 +641,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     uint64_t* ctr = io.out.counters ? io.out.counters + (PHASE == 2 ? (size_t)io.cand_out[blockIdx.y] * MCR_N_COUNTERS : 0) : nullptr;
     if (threadIdx.x == 0 && ctr) {
         atomicAdd((unsigned long long*)&ctr[MCR_CTR_SUCCESS], (unsigned long long)blk[0]);
-        const uint64_t first = (uint64_t)blockIdx.x * kBlock;
+        const uint64_t first = (uint64_t)path_block * kBlock;
         const uint64_t cnt = io.n_paths - first < (uint64_t)kBlock ? io.n_paths - first : (uint64_t)kBlock;
         atomicAdd((unsigned long long*)&ctr[MCR_CTR_PATHS], (unsigned long long)cnt);
     }
@@ -1129,6 +1216,46 @@ static unsigned split_max_waves() {   // (read at every launch: tests compare bo
     const char* e = std::getenv("MCR_K1_SPLIT_MAX_WAVES");
     return (e && *e) ? (unsigned)std::strtoul(e, nullptr, 10) : 3072u;
 }
+// Plan of a time-sliced launch (PHASE 3 of path_kernel): how many path blocks are sliced, into how many segments, at which
+// retirement years.  Resident slots = CUs x 6 workgroups (the count-only variant's occupancy); the slices are equal in COST
+// (an accumulation month is ~0.83 of a retirement month: no withdrawal).
+struct SegmentPlan { int n_split, n_full, q, max_polls, year[kMaxSegments + 1]; };
+static bool plan_segments(const DevParams& d, unsigned n_blocks, SegmentPlan* plan) {
+    int q = 4;
+    if (const char* e = std::getenv("MCR_K1_SEGMENTS")) q = std::atoi(e);
+    if (q < 2) return false;
+    if (q > kMaxSegments) q = kMaxSegments;
+    static int slots_cached = 0;       // (one device model per process in practice; a wrong figure costs time, not results)
+    if (slots_cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        slots_cached = cus * 6;
+    }
+    const unsigned slots = (unsigned)slots_cached;
+    if (n_blocks <= slots || d.retirement_years < 2 * q || d.n_extra_streams > 0 || d.n_lock_slots < d.n_lock_slots_total) return false;
+    // Worth it where the last round of a plain launch is mostly empty: rounds r = blocks / slots, loss of the plain launch up to
+    // ceil(r) / r.  Measured (10^6-path neighbourhood, tools/k1_segments_ab.py): r = 2.54 -3.8 %, 2.29 -7 %, 5.09 -5.6 %, 1.27
+    // -11 %; r = 2.0, 3.0 +2 % (nothing to gain, the extra workgroups cost), 2.8 +1 %, 3.81 0.  MCR_K1_SEGMENTS_ALWAYS=1 (tests).
+    const double r = (double)n_blocks / (double)slots;
+    const char* always = std::getenv("MCR_K1_SEGMENTS_ALWAYS");
+    if (!(always && always[0] == '1') && std::ceil(r) / r < 1.08) return false;
+    plan->max_polls = 20000;            // x ~1 us; a successor is dispatched long after its predecessor has finished
+    if (const char* e = std::getenv("MCR_K1_SEGMENT_POLLS")) plan->max_polls = std::max(0, std::atoi(e));   // (0: every successor recomputes — tests)
+    plan->q = q;
+    plan->n_split = (int)slots;
+    plan->n_full = (int)(n_blocks - slots);
+    const double acc = 0.83 * d.working_months, total = acc + (double)kMPY * d.retirement_years;
+    plan->year[0] = 0;
+    for (int k = 1; k < q; ++k) {
+        int y = (int)std::lround((total * k / q - acc) / kMPY);
+        y = std::max(y, plan->year[k - 1] + (k == 1 ? 0 : 1));
+        plan->year[k] = std::min(y, d.retirement_years - (q - k));
+        if (plan->year[k] < plan->year[k - 1]) return false;
+    }
+    plan->year[q] = d.retirement_years;
+    return true;
+}
+
 static int check_rng(const mcr_rng* rng) {
     if (!rng) { set_error("null rng"); return MCR_ERR_INVALID_ARG; }
     if (rng->kind != MCR_RNG_PHILOX && rng->kind != MCR_RNG_NUMPY) { set_error("unknown rng kind %u", rng->kind); return MCR_ERR_INVALID_ARG; }
@@ -1218,6 +1345,38 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
         if (ex != hipSuccess) return hip_fail(ex, "path_kernel launch (extended streams)");
         if (ef != hipSuccess) return hip_fail(ef, "path_kernel launch (extended streams): side block release");
         return MCR_OK;
+    }
+    // Time-sliced path blocks (PHASE 3 of path_kernel): count-only Philox launches of more than one and at most 64 rounds of
+    // resident workgroups.  MCR_K1_SEGMENTS = segments per sliced block (default 4; 0 or 1 = never).
+    if (mode == 0 && !np_rng && !injected) {
+        SegmentPlan plan;
+        if (plan_segments(d, grid.x, &plan)) {
+            const size_t state_bytes = (size_t)plan.n_split * (size_t)(9 + d.n_lock_slots) * kBlock * sizeof(double);
+            const size_t flag_bytes = (size_t)plan.n_split * (size_t)plan.q * sizeof(unsigned int);
+            void* mem = nullptr;
+            hipError_t e = hipMallocAsync(&mem, state_bytes + flag_bytes, stream);
+            if (e == hipSuccess) {
+                io.snap = (double*)mem;
+                io.seg_flags = (unsigned int*)((char*)mem + state_bytes);
+                io.seg_n_split = plan.n_split; io.seg_n_full = plan.n_full; io.seg_q = plan.q; io.seg_max_polls = plan.max_polls;
+                for (int k = 0; k <= plan.q; ++k) io.seg_year[k] = plan.year[k];
+                e = hipMemsetAsync(io.seg_flags, 0, flag_bytes, stream);
+                const dim3 gseg((unsigned)(plan.n_full + plan.q * plan.n_split));
+#define MCR_LAUNCH_G(T, A) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 3>), gseg, block, lds, stream, d, io, (const DevParams*)nullptr)
+#define MCR_LAUNCH_GA(T) do { if (d.any_annual_tax) MCR_LAUNCH_G(T, true); else MCR_LAUNCH_G(T, false); } while (0)
+                if (e == hipSuccess) {
+                    switch (d.tax_mask) { case 0: MCR_LAUNCH_GA(0); break; case 1: MCR_LAUNCH_GA(1); break; case 2: MCR_LAUNCH_GA(2); break; default: MCR_LAUNCH_GA(3); break; }
+                    e = hipGetLastError();
+                }
+#undef MCR_LAUNCH_GA
+#undef MCR_LAUNCH_G
+                const hipError_t ef = hipFreeAsync(mem, stream);
+                if (e != hipSuccess) return hip_fail(e, "path_kernel launch (time-sliced blocks)");
+                if (ef != hipSuccess) return hip_fail(ef, "path_kernel launch (time-sliced blocks): state release");
+                return MCR_OK;
+            }
+            (void)hipGetLastError();   // (allocation refused: the plain launch below)
+        }
     }
     if (split) {
         const dim3 block2(2 * kBlock);

@@ -1,0 +1,63 @@
+"""Time-sliced path blocks (PHASE 3 of the path kernel; csrc/mcr_hip.hip): count-only launches of a few rounds of
+workgroups cut the first blocks of the launch into segments at retirement-year boundaries, dispatched so that the small work
+items come last.  A segment hands its lanes' state over through memory; a successor that does not see its predecessor's flag
+recomputes the block itself.  Whatever the route — plain launch, sliced, sliced with every successor recomputing — the
+counters, year bins and histogram bins must be the same integers."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from monte_carlo_retirement_amd import Config, params_from_config
+from monte_carlo_retirement_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ("MCR_K1_SEGMENTS", "MCR_K1_SEGMENTS_ALWAYS", "MCR_K1_SEGMENT_POLLS")
+
+
+def _run(p, wm, n, begin, env, edges):
+    old = {k: os.environ.get(k) for k in KNOBS}
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        r = E.run_batch_host(p, 4242, 1, begin, n, wm, want_summary=False, want_trajectories=False, hist_edges=edges)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    return np.concatenate([r["counters"], r["ruin_year_bins"], r["wr_obs_counts"], r["hist_bins"]]).astype(np.int64)
+
+
+def _scenarios():
+    inj = {g["name"]: g for g in load_golden("paths_injected.json")}
+    c1 = inj["C1_config_json_wm233"]["cfg"]                       # one frozen stream (a lock column travels with the state)
+    annual = inj["ANNUAL_wm50"]["cfg"]                            # annual-gains tax: the gain accumulators travel too
+    failing = inj["FAILING_wm24"]["cfg"]                          # half of the paths fail: dead lanes and dead waves cross segments
+    yield "config.json wm=233 (odd resume rows, terminal tax period)", c1, 233
+    yield "config.json wm=240", c1, 240
+    yield "annual tax wm=50", annual, 50
+    yield "failing wm=24", failing, 24
+    yield "failing wm=7", dict(failing, retirement_years=9), 7    # fewer years than 2 x the default segment count: q is lowered or the plain launch runs
+
+
+@pytest.mark.parametrize("n", [400_000, 393_216 + 999])
+def test_sliced_launch_counts_equal_the_plain_launch(n):
+    edges = np.geomspace(1.0, 1e13, 65)
+    for name, cfgd, wm in _scenarios():
+        p = params_from_config(Config(**cfgd))
+        plain = _run(p, wm, n, 2**33 + 5, {"MCR_K1_SEGMENTS": "0"}, edges)
+        assert int(plain[1]) == n and 0 < int(plain[0]) <= n, name
+        for env in ({"MCR_K1_SEGMENTS_ALWAYS": "1"},                                    # 4 segments, hand-over through memory
+                    {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "2"},
+                    {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "7"},
+                    {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENT_POLLS": "0"},       # every successor recomputes its block from month 0
+                    {}):                                                               # the launcher's own rule
+            got = _run(p, wm, n, 2**33 + 5, env, edges)
+            assert np.array_equal(got, plain), (name, n, env, np.nonzero(got != plain)[0][:8].tolist())
