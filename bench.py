@@ -724,7 +724,8 @@ def main():
                 "devices": devices_seen,           # every rank's own report (all_gather_object)
             },
             "roofline": {
-                "kernel": "mcr::path_kernel<0, 0, 3, false, false, 0, false, false>  (MODE 0 count-only, Philox, realized-gains tax on both assets, no annual tax, unsplit, by-value stream block)",
+                "kernel": "mcr::path_kernel<0, 0, 3, false, false, 3, false, false, false>  (MODE 0 count-only, Philox, realized-gains tax on both assets, no annual tax, "
+                          "PHASE 3 = time-sliced path blocks: the form launches of 10^6 paths take; <..., 0, ...> = the plain launch of other sizes)",
                 "bound": "valu_fp64",
                 "achieved": achieved_t,
                 "peak": FP64_LANE_OPS_PEAK_T,

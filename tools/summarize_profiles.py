@@ -19,9 +19,13 @@ PATHS_COUNT, MONTHS_COUNT = 1_000_000, 833            # bench.py workload (confi
 PATHS_FULL, T_FULL, RY_FULL = 10_000_000, 48, 40       # bench.py hbm_kernels block (configs[2] shape)
 
 
+import re
+HEADLINE = re.compile(r"path_kernel<0, 0, 3, false, false, [03], false")
+
+
 def label(kernel_name: str):
     k = kernel_name
-    if "path_kernel<0, 0, 3, false, false, 0, false" in k:      # the headline variant (Philox, whole path, unsplit)
+    if HEADLINE.search(k):      # the headline variant (Philox, unsplit; PHASE 3 = time-sliced blocks at the bench's 10^6 paths, PHASE 0 = plain)
         return "K1 path_kernel<0,...> (count-only, 1e6 paths x 833 months)"
     if "path_kernel<0, 1," in k:
         return "K1 path_kernel<0,1,...> (count-only, NumPy stream, 1e6 paths x 833 months)"
@@ -61,16 +65,19 @@ def main(src: str, dst: str) -> None:
     m = lambda k, c: k[c]["mean_per_launch"]
     wave_months = (PATHS_COUNT / 64) * MONTHS_COUNT
     stat_rows = list(csv.DictReader(open(stats)))
-    HEAD = "path_kernel<0, 0, 3, false, false, 0, false"
-    k1_mean_all_ms = next(float(r["AverageNs"]) for r in stat_rows if HEAD in r["Name"]) / 1e6
+    # (the kernel with the most calls among the headline variants: the bench's count-only step)
+    head_rows = sorted((r for r in stat_rows if HEADLINE.search(r["Name"])), key=lambda r: -int(r["Calls"]))
+    k1_mean_all_ms = float(head_rows[0]["AverageNs"]) / 1e6
+    k1_name = head_rows[0]["Name"]
     # The figure to compare with bench.py's HIP-event `kernel_ms`: the MEDIAN over the timed launches of the traced run
     # (tools/kernel_trace_medians.py, computed on the box from the kernel-trace CSV); rocprof's --stats mean includes the warm-up
     # launches (round 3: 7.21 ms mean over 12 launches, max 8.39, against 6.8-7.0 in every bench run).
     med = json.load(open(os.path.join(src, "kt_medians.json")))["kernels"]
-    k1_med = next(v for k, v in med.items() if HEAD in k)
+    k1_med = med[k1_name] if k1_name in med else next(v for k, v in med.items() if HEADLINE.search(k))
     k1_ms = k1_med["median_timed_ms"]
     alg_full = PATHS_FULL * (8 * (2 * T_FULL + RY_FULL + 6) + 1)
     derived = {
+        "K1_count_kernel": k1_name,
         "K1_count_median_timed_ms_from_kernel_trace": k1_ms,
         "K1_count_timed_launches": {k: k1_med[k] for k in ("timed_calls", "skipped_warmup_calls", "min_timed_ms", "max_timed_ms", "mean_timed_ms")},
         "K1_count_avg_ms_from_kernel_stats_all_launches": k1_mean_all_ms,
