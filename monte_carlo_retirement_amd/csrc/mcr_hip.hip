@@ -1221,10 +1221,9 @@ static unsigned split_max_waves() {   // (read at every launch: tests compare bo
 // (an accumulation month is ~0.83 of a retirement month: no withdrawal).
 struct SegmentPlan { int n_split, n_full, q, max_polls, year[kMaxSegments + 1]; };
 static bool plan_segments(const DevParams& d, unsigned n_blocks, SegmentPlan* plan) {
-    int q = 4;
+    int q = -1;     // (chosen below from the shape of the launch unless the environment says otherwise)
     if (const char* e = std::getenv("MCR_K1_SEGMENTS")) q = std::atoi(e);
-    if (q < 2) return false;
-    if (q > kMaxSegments) q = kMaxSegments;
+    if (q >= 0 && q < 2) return false;
     static int slots_cached = 0;       // (one device model per process in practice; a wrong figure costs time, not results)
     if (slots_cached == 0) {
         int dev = 0, cus = 0;
@@ -1232,7 +1231,9 @@ static bool plan_segments(const DevParams& d, unsigned n_blocks, SegmentPlan* pl
         slots_cached = cus * 6;
     }
     const unsigned slots = (unsigned)slots_cached;
-    if (n_blocks <= slots || d.retirement_years < 2 * q || d.n_extra_streams > 0 || d.n_lock_slots < d.n_lock_slots_total) return false;
+    if (n_blocks <= slots || d.retirement_years < 4 || d.n_extra_streams > 0 || d.n_lock_slots < d.n_lock_slots_total) return false;
+    if (q < 0) q = n_blocks < 2 * slots ? 8 : 6;     // (measured: 500 000 paths 3.12 ms plain, 2.77 with 4 segments, 2.58 with 6; 10^6 and 2 10^6: 6 = 4 - 0.4 %)
+    q = std::min(std::min(q, kMaxSegments), d.retirement_years / 2);
     // Worth it where the last round of a plain launch is mostly empty: rounds r = blocks / slots, loss of the plain launch up to
     // ceil(r) / r.  Measured (10^6-path neighbourhood, tools/k1_segments_ab.py): r = 2.54 -3.8 %, 2.29 -7 %, 5.09 -5.6 %, 1.27
     // -11 %; r = 2.0, 3.0 +2 % (nothing to gain, the extra workgroups cost), 2.8 +1 %, 3.81 0.  MCR_K1_SEGMENTS_ALWAYS=1 (tests).

@@ -44,7 +44,7 @@ def _scenarios():
     yield "config.json wm=240", c1, 240
     yield "annual tax wm=50", annual, 50
     yield "failing wm=24", failing, 24
-    yield "failing wm=7", dict(failing, retirement_years=9), 7    # fewer years than 2 x the default segment count: q is lowered or the plain launch runs
+    yield "failing wm=7", dict(failing, retirement_years=9), 7    # fewer years than 2 x the segment count: the count is lowered to 4
 
 
 @pytest.mark.parametrize("n", [400_000, 393_216 + 999])
@@ -54,7 +54,8 @@ def test_sliced_launch_counts_equal_the_plain_launch(n):
         p = params_from_config(Config(**cfgd))
         plain = _run(p, wm, n, 2**33 + 5, {"MCR_K1_SEGMENTS": "0"}, edges)
         assert int(plain[1]) == n and 0 < int(plain[0]) <= n, name
-        for env in ({"MCR_K1_SEGMENTS_ALWAYS": "1"},                                    # 4 segments, hand-over through memory
+        for env in ({"MCR_K1_SEGMENTS_ALWAYS": "1"},                                    # the launcher's segment count, hand-over through memory
+                    {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "4"},
                     {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "2"},
                     {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "7"},
                     {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENT_POLLS": "0"},       # every successor recomputes its block from month 0
