@@ -74,10 +74,7 @@ struct RqBracket {
     unsigned int lut_ok;
     unsigned int lut_pad;
 };
-#ifndef MCR_RQ_LUT_SIZE
-#define MCR_RQ_LUT_SIZE 2048
-#endif
-constexpr int kRqLutSize = MCR_RQ_LUT_SIZE;
+constexpr int kRqLutSize = 2048;
 constexpr int kRqTiny = 4096;              // first sample: sorted in LDS by one workgroup per row
 constexpr double kRqCoarseSigmas = 7.0;    // its brackets leave room for the second sample's own 5-sigma window
 constexpr int kRqMaxSubBins = 1024;        // sub-histogram bins per interval (stride of the global histograms)

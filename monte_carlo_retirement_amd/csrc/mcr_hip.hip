@@ -85,9 +85,6 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // accumulation months for every probed candidate although, under common random numbers, they do not depend on it,
 // :513-579): PHASE 1 runs the accumulation once to the largest candidate and stores the state at the end of every
 // candidate month; PHASE 2 (grid.y = candidate) resumes each candidate's decumulation from its snapshot.
-#ifndef MCR_K1_WAVES_ATTR
-#define MCR_K1_WAVES_ATTR
-#endif
 // SPLIT = true (count-only Philox variants; launches that leave SIMDs idle — a lone 50 000-path search probe is 782
 // wavefronts on 1 024 SIMDs and runs at ~12 cycles per instruction, latency-bound): the workgroup has 2 x kBlock threads
 // for its kBlock paths.  Threads kBlock .. 2 kBlock - 1 are PRODUCERS: they run growth_rows2 (Philox, Box-Muller, exp) one
@@ -119,7 +116,7 @@ constexpr bool kExactMonthDefault = true;
 constexpr bool kExactMonthDefault = false;
 #endif
 template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false, bool XS = false, bool EXACT = kExactMonthDefault>
-__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && (PHASE == 0 || PHASE == 3)) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) MCR_K1_WAVES_ATTR void path_kernel(const DevParams P_arg, const KernelIO io,
+__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && (PHASE == 0 || PHASE == 3)) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
     static_assert(!XS || (PHASE == 0 && !SPLIT && TAXED == 3 && ANNUAL), "extended stream lists run the generic whole-path form");
