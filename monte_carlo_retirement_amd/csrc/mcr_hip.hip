@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_bits(double* p, unsigned long long bits) {
 // halves of a month's dependency chain then run on different SIMDs of the CU.  One workgroup barrier per pair of months
 // hands a buffer over; every wave executes the same number of them (no early exit when all lanes have failed) or has
 // terminated.  The arithmetic of every path is unchanged: counts are bit-identical to SPLIT = false.
-// PHASE 3 (count-only Philox launches of a few rounds of workgroups; launch_paths): TIME-SLICED path blocks.  A launch of B
+// PHASE 3 (Philox launches of a few rounds of workgroups, any output mode; launch_paths): TIME-SLICED path blocks.  A launch of B
 // equal workgroups on W resident slots ends when the busiest slot has run ceil(B / W) of them: 10^6 paths are 15.26 workgroups
 // per CU-slot, so the chip idles through most of a sixteenth round (measured: 5.15 ms where 4.77 would do, LABNOTES R4.6).
 // Small work items at the END of the dispatch order fix that (longest-processing-time-first): the first S path blocks of the
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
     static_assert(!XS || (PHASE == 0 && !SPLIT && TAXED == 3 && ANNUAL), "extended stream lists run the generic whole-path form");
-    static_assert(PHASE != 3 || (MODE == 0 && RNG == 0 && !INJ && !SPLIT && !XS), "time-sliced blocks exist for the count-only Philox variants");
+    static_assert(PHASE != 3 || (RNG == 0 && !INJ && !SPLIT && !XS), "time-sliced blocks exist for the plain Philox variants");
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
@@ -324,7 +324,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         if (wm & 1) begin_month(wm - 1);   // the pair of rows (wm - 1, wm) was staged during the accumulation: stage it again
     }
     // PHASE 3: a later segment of a time-sliced block takes its lanes' state over from its predecessor
-    constexpr int kSegFixedFields = 9;     // b1 b2 c1 c2 gacc1 gacc2 infl | flags | Philox carry; then the lock columns
+    // b1 b2 c1 c2 gacc1 gacc2 infl | flags | Philox carry | (per-path outputs: balance and price level at retirement, the
+    // three write-once columns) ; then the lock columns
+    constexpr int kSegFixedFields = MODE >= 1 ? 14 : 9;
+    double seg_start_balance = 0.0, seg_infl_ret = 0.0;
     auto seg_at = [&](int f) { return io.snap + ((size_t)seg_block * (size_t)(kSegFixedFields + P.n_lock_slots) + (size_t)f) * kBlock + (size_t)tid; };
     __shared__ int seg_ok_s;
     bool seg_resumed = false;
@@ -353,6 +356,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
                 const unsigned long long cw = f64_bits(*seg_at(8));
                 carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
                 for (int k = 0; k < P.n_lock_slots; ++k) lock_lds[(size_t)k * kBlock + tid] = *seg_at(kSegFixedFields + k);
+                if (MODE >= 1) {
+                    seg_start_balance = *seg_at(9); seg_infl_ret = *seg_at(10);
+                    sum_col[0] = *seg_at(11); sum_col[kBlock] = *seg_at(12); sum_col[2 * kBlock] = *seg_at(13);
+                }
                 y_begin = io.seg_year[seg];
                 const int r0 = wm + kMPY * y_begin;
                 if (r0 >= prio_t3) __builtin_amdgcn_s_setprio(0);
@@ -386,16 +393,17 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         if (PHASE == 1 && snap_i < io.n_snap && m == io.snap_months[snap_i]) save_snapshot();
     }
     if (PHASE == 1) return;   // (every thread of the workgroup: nothing below is needed)
-    const double start_balance = b1 + b2;  // :581
-    const double infl_ret = infl;          // :582
-    if (wm > 0 && wm % kMPY != 0) put_sample(t_idx++, start_balance, infl_ret);  // :590-594
+    double start_balance = b1 + b2;        // :581
+    double infl_ret = infl;                // :582
+    if (PHASE == 3 && seg_resumed) { start_balance = seg_start_balance; infl_ret = seg_infl_ret; t_idx = P.trajectory_len - ry + y_begin; }
+    else if (wm > 0 && wm % kMPY != 0) put_sample(t_idx++, start_balance, infl_ret);  // :590-594
 
     // ---- decumulation (:632-868) ----
     double fy_gross = 0.0, fy_real = 0.0;            // :623-624
     bool alive = !pre_fail;                          // :627, :633
     bool succeeded = !pre_fail;
     unsigned long long ytr_bits = pre_fail ? f64_bits(0.0) : kNanBits;  // YearsToRuin (:497, :628-629)
-    if (kSumLds) { sum_col[0] = 0.0; sum_col[kBlock] = 0.0; store_bits(&sum_col[2 * kBlock], ytr_bits); }
+    if (kSumLds && !(PHASE == 3 && seg_resumed)) { sum_col[0] = 0.0; sum_col[kBlock] = 0.0; store_bits(&sum_col[2 * kBlock], ytr_bits); }
     // A launch that cannot fill the chip (SPLIT) is bound by each wave's dependency chain, and re-reading a stream's record
     // from the kernel arguments every month is three dependent scalar loads on it (the compiler loads start, then end, then
     // the rest): the first two records stay in SGPRs there (82 + 16 of them; the unsplit kernel has none to spare).
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         ++t_idx;
         if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], wr_bits);  // :851, :859, :934-935
     }
-    for (; year < ry; ++year) {  // the whole wave failed early: pad (:902-916, :934-935)
+    for (; year < (PHASE == 3 ? y_end : ry); ++year) {  // the whole wave failed early: pad (:902-916, :934-935)
         put_sample(t_idx++, 0.0, infl);
         if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], kNanBits);
     }
@@ -573,6 +581,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         store_bits(seg_at(7), (alive ? 1ull : 0ull) | (succeeded ? 2ull : 0ull) | ((unsigned long long)(ruin_bin + 1) << 8) | ((unsigned long long)done_years << 24));
         store_bits(seg_at(8), ((unsigned long long)carry.w3 << 32) | (unsigned long long)carry.w2);
         for (int k = 0; k < P.n_lock_slots; ++k) *seg_at(kSegFixedFields + k) = lock_lds[(size_t)k * kBlock + tid];
+        if (MODE >= 1) {
+            *seg_at(9) = start_balance; *seg_at(10) = infl_ret;
+            *seg_at(11) = sum_col[0]; *seg_at(12) = sum_col[kBlock]; *seg_at(13) = sum_col[2 * kBlock];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (threadIdx.x == 0)
@@ -1214,20 +1226,20 @@ static unsigned split_max_waves() {   // (read at every launch: tests compare bo
     return (e && *e) ? (unsigned)std::strtoul(e, nullptr, 10) : 3072u;
 }
 // Plan of a time-sliced launch (PHASE 3 of path_kernel): how many path blocks are sliced, into how many segments, at which
-// retirement years.  Resident slots = CUs x 6 workgroups (the count-only variant's occupancy); the slices are equal in COST
+// retirement years.  Resident slots = CUs x 6 workgroups (count-only) or x 5 (variants with per-path outputs); the slices are equal in COST
 // (an accumulation month is ~0.83 of a retirement month: no withdrawal).
 struct SegmentPlan { int n_split, n_full, q, max_polls, year[kMaxSegments + 1]; };
-static bool plan_segments(const DevParams& d, unsigned n_blocks, SegmentPlan* plan) {
+static bool plan_segments(const DevParams& d, unsigned n_blocks, int mode, SegmentPlan* plan) {
     int q = -1;     // (chosen below from the shape of the launch unless the environment says otherwise)
     if (const char* e = std::getenv("MCR_K1_SEGMENTS")) q = std::atoi(e);
     if (q >= 0 && q < 2) return false;
-    static int slots_cached = 0;       // (one device model per process in practice; a wrong figure costs time, not results)
-    if (slots_cached == 0) {
+    static int cus_cached = 0;         // (one device model per process in practice; a wrong figure costs time, not results)
+    if (cus_cached == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
-        slots_cached = cus * 6;
+        cus_cached = cus;
     }
-    const unsigned slots = (unsigned)slots_cached;
+    const unsigned slots = (unsigned)cus_cached * (mode == 0 ? 6u : 5u);     // resident workgroups: the variants' launch bounds
     if (n_blocks <= slots || d.retirement_years < 4 || d.n_extra_streams > 0 || d.n_lock_slots < d.n_lock_slots_total) return false;
     if (q < 0) q = n_blocks < 2 * slots ? 8 : 6;     // (measured: 500 000 paths 3.12 ms plain, 2.77 with 4 segments, 2.58 with 6; 10^6 and 2 10^6: 6 = 4 - 0.4 %)
     q = std::min(std::min(q, kMaxSegments), d.retirement_years / 2);
@@ -1344,12 +1356,12 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
         if (ef != hipSuccess) return hip_fail(ef, "path_kernel launch (extended streams): side block release");
         return MCR_OK;
     }
-    // Time-sliced path blocks (PHASE 3 of path_kernel): count-only Philox launches of more than one and at most 64 rounds of
-    // resident workgroups.  MCR_K1_SEGMENTS = segments per sliced block (default 4; 0 or 1 = never).
-    if (mode == 0 && !np_rng && !injected) {
+    // Time-sliced path blocks (PHASE 3 of path_kernel): Philox launches of a few rounds of resident workgroups whose last round
+    // would be mostly empty (plan_segments).  MCR_K1_SEGMENTS = segments per sliced block (default 6 or 8; 0 or 1 = never).
+    if (!np_rng && !injected && !xs && !split) {
         SegmentPlan plan;
-        if (plan_segments(d, grid.x, &plan)) {
-            const size_t state_bytes = (size_t)plan.n_split * (size_t)(9 + d.n_lock_slots) * kBlock * sizeof(double);
+        if (plan_segments(d, grid.x, mode, &plan)) {
+            const size_t state_bytes = (size_t)plan.n_split * (size_t)((mode >= 1 ? 14 : 9) + d.n_lock_slots) * kBlock * sizeof(double);
             const size_t flag_bytes = (size_t)plan.n_split * (size_t)plan.q * sizeof(unsigned int);
             void* mem = nullptr;
             hipError_t e = hipMallocAsync(&mem, state_bytes + flag_bytes, stream);
@@ -1360,7 +1372,8 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
                 for (int k = 0; k <= plan.q; ++k) io.seg_year[k] = plan.year[k];
                 e = hipMemsetAsync(io.seg_flags, 0, flag_bytes, stream);
                 const dim3 gseg((unsigned)(plan.n_full + plan.q * plan.n_split));
-#define MCR_LAUNCH_G(T, A) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 3>), gseg, block, lds, stream, d, io, (const DevParams*)nullptr)
+#define MCR_LAUNCH_GM(M, T, A) hipLaunchKernelGGL((path_kernel<M, 0, T, A, false, 3>), gseg, block, lds, stream, d, io, (const DevParams*)nullptr)
+#define MCR_LAUNCH_G(T, A) do { if (mode == 2) MCR_LAUNCH_GM(2, T, A); else if (mode == 1) MCR_LAUNCH_GM(1, T, A); else MCR_LAUNCH_GM(0, T, A); } while (0)
 #define MCR_LAUNCH_GA(T) do { if (d.any_annual_tax) MCR_LAUNCH_G(T, true); else MCR_LAUNCH_G(T, false); } while (0)
                 if (e == hipSuccess) {
                     switch (d.tax_mask) { case 0: MCR_LAUNCH_GA(0); break; case 1: MCR_LAUNCH_GA(1); break; case 2: MCR_LAUNCH_GA(2); break; default: MCR_LAUNCH_GA(3); break; }
@@ -1368,6 +1381,7 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
                 }
 #undef MCR_LAUNCH_GA
 #undef MCR_LAUNCH_G
+#undef MCR_LAUNCH_GM
                 const hipError_t ef = hipFreeAsync(mem, stream);
                 if (e != hipSuccess) return hip_fail(e, "path_kernel launch (time-sliced blocks)");
                 if (ef != hipSuccess) return hip_fail(ef, "path_kernel launch (time-sliced blocks): state release");

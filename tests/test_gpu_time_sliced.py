@@ -62,3 +62,34 @@ def test_sliced_launch_counts_equal_the_plain_launch(n):
                     {}):                                                               # the launcher's own rule
             got = _run(p, wm, n, 2**33 + 5, env, edges)
             assert np.array_equal(got, plain), (name, n, env, np.nonzero(got != plain)[0][:8].tolist())
+
+
+def _run_outputs(p, wm, n, begin, env, want_trajectories):
+    old = {k: os.environ.get(k) for k in KNOBS}
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        return E.run_batch_host(p, 4242, 1, begin, n, wm, want_trajectories=want_trajectories)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("want_trajectories", [False, True])
+def test_sliced_launch_outputs_equal_the_plain_launch(want_trajectories):
+    """The variants with per-path outputs slice too (their occupancy is five workgroups per CU: 10^6 paths are 3.05 rounds): the
+    hand-over state also carries the balance and price level at retirement and the three write-once columns; every per-path
+    field, trajectory sample and withdrawal rate must come out bit-identical, whichever segment wrote it."""
+    n = 330_000                      # 1 290 path blocks on 1 280 resident slots
+    for name, cfgd, wm in _scenarios():
+        p = params_from_config(Config(**cfgd))
+        plain = _run_outputs(p, wm, n, 7, {"MCR_K1_SEGMENTS": "0"}, want_trajectories)
+        for env in ({"MCR_K1_SEGMENTS_ALWAYS": "1"}, {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "3"},
+                    {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENT_POLLS": "0"}, {}):
+            got = _run_outputs(p, wm, n, 7, env, want_trajectories)
+            assert set(got) == set(plain)
+            for k in plain:
+                assert np.array_equal(got[k], plain[k], equal_nan=True), (name, env, k)
