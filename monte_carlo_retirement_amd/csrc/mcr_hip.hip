@@ -58,6 +58,8 @@ struct KernelIO {
     // PHASE 3 (time-sliced path blocks, see path_kernel): the first seg_n_split path blocks of the launch are cut into seg_q
     // segments at retirement-year boundaries; `snap` holds their hand-over state, seg_flags says which segments are done
     int32_t seg_n_split, seg_n_full, seg_q;
+    int32_t seg_blocks_per_cand;                     // PHASE 4: path blocks per search candidate (the launch lists candidate-major)
+    double* seg_state;                               // [seg_n_split][fields][kBlock] hand-over state
     int32_t seg_year[kMaxSegments + 1];              // segment k covers retirement years [seg_year[k], seg_year[k + 1]); segment 0 also the accumulation
     unsigned int* seg_flags;                         // [seg_n_split][seg_q], zeroed before the launch
     int32_t seg_max_polls;                           // x ~1 us: how long a successor looks for its predecessor's flag before it recomputes the block itself
@@ -116,11 +118,16 @@ constexpr bool kExactMonthDefault = true;
 constexpr bool kExactMonthDefault = false;
 #endif
 template <int MODE, int RNG, int TAXED, bool ANNUAL, bool INJ = false, int PHASE = 0, bool SPLIT = false, bool XS = false, bool EXACT = kExactMonthDefault>
-__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && (PHASE == 0 || PHASE == 3)) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) void path_kernel(const DevParams P_arg, const KernelIO io,
+__global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0 && RNG == 0 && (PHASE == 0 || PHASE == 3 || PHASE == 4)) ? 6 : ((MODE == 1 || MODE == 2) && RNG == 0 && !INJ) ? 5 : 4) void path_kernel(const DevParams P_arg, const KernelIO io,
                                                          const DevParams* __restrict__ cand_params) {
     static_assert(!SPLIT || (MODE == 0 && RNG == 0 && !INJ), "the producer / consumer split exists for the count-only Philox variants");
     static_assert(!XS || (PHASE == 0 && !SPLIT && TAXED == 3 && ANNUAL), "extended stream lists run the generic whole-path form");
-    static_assert(PHASE != 3 || (RNG == 0 && !INJ && !SPLIT && !XS), "time-sliced blocks exist for the plain Philox variants");
+    // PHASE 4 = PHASE 2 (a candidate's decumulation resumed from its accumulation snapshot) time-sliced like PHASE 3: the
+    // 17-month verification window of the search is 17 x 196 workgroups = 2.17 rounds of the resident slots.
+    constexpr bool kCand = PHASE == 2 || PHASE == 4;      // resumes a search candidate from its snapshot; per-candidate parameter block
+    constexpr bool kSliced = PHASE == 3 || PHASE == 4;    // time-sliced path blocks
+    static_assert(!kSliced || (RNG == 0 && !INJ && !SPLIT && !XS), "time-sliced blocks exist for the plain Philox variants");
+    static_assert(PHASE != 4 || MODE == 0, "the search probes count only");
     // TAXED: which assets carry an effective realized-gains rate (bit 0: inv1, bit 1: inv2; DevParams::tax_mask)
     static_assert(TAXED >= 0 && TAXED <= 3, "TAXED is a two-bit mask");
     constexpr bool T1 = (TAXED & 1) != 0, T2 = (TAXED & 2) != 0, TANY = TAXED != 0;
@@ -132,7 +139,18 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     const bool producer = SPLIT && threadIdx.x >= (unsigned)kBlock;                  // wave-uniform (kBlock = 4 wavefronts)
     // PHASE 2: the parameter block of candidate blockIdx.y, in device memory (a separate const __restrict__ kernel
     // argument so that its loads are provably invariant and uniform: scalar loads, like the by-value block)
-    const DevParams& P = PHASE == 2 ? cand_params[blockIdx.y] : P_arg;
+    // time-sliced launches (1-D grid): which path block (of which candidate) and which segment of it this workgroup runs (seg < 0: a whole block)
+    int seg = -1, seg_block = 0;
+    unsigned int path_block = blockIdx.x, cand = PHASE == 2 ? blockIdx.y : 0u;
+    if (kSliced) {
+        const int S = io.seg_n_split, F = io.seg_n_full, bid = (int)blockIdx.x;
+        unsigned int lb = (unsigned)bid;                  // the block's position in the launch's list of (candidate, path block) pairs
+        if (bid < S) { seg = 0; seg_block = bid; }
+        else if (bid >= S + F) { const int k = bid - S - F; seg = 1 + k / S; seg_block = k % S; lb = (unsigned)seg_block; }
+        if (PHASE == 4) { cand = lb / (unsigned)io.seg_blocks_per_cand; path_block = lb % (unsigned)io.seg_blocks_per_cand; }
+        else path_block = lb;
+    }
+    const DevParams& P = kCand ? cand_params[cand] : P_arg;
     // LDS.  STATIC: the math tables (mcr_math.h) and, for the Philox stream, the [6][kBlock] stage of two months' gross
     // factors — static because the compiler then knows their addresses (offset 0 ...) and a table lookup is index << 3 +
     // ds_read with an immediate offset; against the dynamic region every address is `base + ...` with a base it only learns
@@ -172,15 +190,6 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     for (int k = threadIdx.x; k < n_blk + n_hist; k += kThreads) blk[k] = 0u;
     __syncthreads();
 
-    // PHASE 3: which path block and which segment of it this workgroup runs (seg < 0: a whole block)
-    int seg = -1, seg_block = 0;
-    unsigned int path_block = blockIdx.x;
-    if (PHASE == 3) {
-        const int S = io.seg_n_split, F = io.seg_n_full, bid = (int)blockIdx.x;
-        if (bid < S) { seg = 0; seg_block = bid; path_block = (unsigned)bid; }
-        else if (bid < S + F) { path_block = (unsigned)bid; }
-        else { const int k = bid - S - F; seg = 1 + k / S; seg_block = k % S; path_block = (unsigned)seg_block; }
-    }
     const uint64_t local = (uint64_t)path_block * kBlock + (unsigned)tid;
     const bool valid = local < io.n_paths;
     const uint64_t li = valid ? local : (io.n_paths - 1);  // tail lanes shadow the last path, write nothing
@@ -314,26 +323,17 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         return;
     }
     if (PHASE == 1) while (snap_i < io.n_snap && io.snap_months[snap_i] == 0) save_snapshot();
-    if (PHASE == 2) {
-        const int c = blockIdx.y;
-        b1 = *snap_at(c, 0); b2 = *snap_at(c, 1); c1 = *snap_at(c, 2); c2 = *snap_at(c, 3);
-        gacc1 = *snap_at(c, 4); gacc2 = *snap_at(c, 5); infl = *snap_at(c, 6); contrib = *snap_at(c, 7);
-        pre_fail = *snap_at(c, 8) != 0.0;
-        const unsigned long long cw = f64_bits(*snap_at(c, 9));
-        carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
-        if (wm & 1) begin_month(wm - 1);   // the pair of rows (wm - 1, wm) was staged during the accumulation: stage it again
-    }
     // PHASE 3: a later segment of a time-sliced block takes its lanes' state over from its predecessor
     // b1 b2 c1 c2 gacc1 gacc2 infl | flags | Philox carry | (per-path outputs: balance and price level at retirement, the
     // three write-once columns) ; then the lock columns
     constexpr int kSegFixedFields = MODE >= 1 ? 14 : 9;
     double seg_start_balance = 0.0, seg_infl_ret = 0.0;
-    auto seg_at = [&](int f) { return io.snap + ((size_t)seg_block * (size_t)(kSegFixedFields + P.n_lock_slots) + (size_t)f) * kBlock + (size_t)tid; };
+    auto seg_at = [&](int f) { return io.seg_state + ((size_t)seg_block * (size_t)(kSegFixedFields + P.n_lock_slots) + (size_t)f) * kBlock + (size_t)tid; };
     __shared__ int seg_ok_s;
     bool seg_resumed = false;
     int y_begin = 0, y_end = ry;
     unsigned long long seg_state_flags = 0ull;
-    if (PHASE == 3 && seg >= 0) {
+    if (kSliced && seg >= 0) {
         y_end = io.seg_year[seg + 1];
         if (seg > 0) {
             if (threadIdx.x == 0) {
@@ -370,8 +370,17 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         }
     }
 
+    if (kCand && !seg_resumed) {   // (a segment that took its predecessor's state over needs neither the snapshot nor the re-staged pair)
+        const int c = (int)cand;
+        b1 = *snap_at(c, 0); b2 = *snap_at(c, 1); c1 = *snap_at(c, 2); c2 = *snap_at(c, 3);
+        gacc1 = *snap_at(c, 4); gacc2 = *snap_at(c, 5); infl = *snap_at(c, 6); contrib = *snap_at(c, 7);
+        pre_fail = *snap_at(c, 8) != 0.0;
+        const unsigned long long cw = f64_bits(*snap_at(c, 9));
+        carry.w2 = (uint32_t)cw; carry.w3 = (uint32_t)(cw >> 32);
+        if (wm & 1) begin_month(wm - 1);   // the pair of rows (wm - 1, wm) was staged during the accumulation: stage it again
+    }
     // ---- accumulation (:513-579): no lane leaves this loop early ----
-    for (int m = 1; m <= ((PHASE == 2 || (PHASE == 3 && seg_resumed)) ? 0 : wm); ++m) {
+    for (int m = 1; m <= ((kCand || (kSliced && seg_resumed)) ? 0 : wm); ++m) {
         if (P.contrib_grows && (m - 1) % kMPY == 0 && m > 1) {  // :514-517 (wave-uniform: a scalar branch, not a select)
             asm volatile("");
             contrib *= P.contrib_growth_factor;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     if (PHASE == 1) return;   // (every thread of the workgroup: nothing below is needed)
     double start_balance = b1 + b2;        // :581
     double infl_ret = infl;                // :582
-    if (PHASE == 3 && seg_resumed) { start_balance = seg_start_balance; infl_ret = seg_infl_ret; t_idx = P.trajectory_len - ry + y_begin; }
+    if (kSliced && seg_resumed) { start_balance = seg_start_balance; infl_ret = seg_infl_ret; t_idx = P.trajectory_len - ry + y_begin; }
     else if (wm > 0 && wm % kMPY != 0) put_sample(t_idx++, start_balance, infl_ret);  // :590-594
 
     // ---- decumulation (:632-868) ----
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     bool alive = !pre_fail;                          // :627, :633
     bool succeeded = !pre_fail;
     unsigned long long ytr_bits = pre_fail ? f64_bits(0.0) : kNanBits;  // YearsToRuin (:497, :628-629)
-    if (kSumLds && !(PHASE == 3 && seg_resumed)) { sum_col[0] = 0.0; sum_col[kBlock] = 0.0; store_bits(&sum_col[2 * kBlock], ytr_bits); }
+    if (kSumLds && !(kSliced && seg_resumed)) { sum_col[0] = 0.0; sum_col[kBlock] = 0.0; store_bits(&sum_col[2 * kBlock], ytr_bits); }
     // A launch that cannot fill the chip (SPLIT) is bound by each wave's dependency chain, and re-reading a stream's record
     // from the kernel arguments every month is three dependent scalar loads on it (the compiler loads start, then end, then
     // the rest): the first two records stay in SGPRs there (82 + 16 of them; the unsplit kernel has none to spare).
@@ -423,14 +432,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
     int ruin_bin = pre_fail ? 0 : -1;
     int done_years = 0;  // completed (observed) retirement years = non-NaN WR entries
     int year = 0;
-    if (PHASE == 3 && seg_resumed) {   // flags of the hand-over state: alive | succeeded << 1 | (ruin_bin + 1) << 8 | done_years << 24
+    if (kSliced && seg_resumed) {   // flags of the hand-over state: alive | succeeded << 1 | (ruin_bin + 1) << 8 | done_years << 24
         alive = (seg_state_flags & 1ull) != 0ull;
         succeeded = (seg_state_flags & 2ull) != 0ull;
         ruin_bin = (int)((seg_state_flags >> 8) & 0xFFFFull) - 1;
         done_years = (int)(seg_state_flags >> 24);
         year = y_begin;
     }
-    for (; year < (PHASE == 3 ? y_end : ry); ++year) {
+    for (; year < (kSliced ? y_end : ry); ++year) {
         if (!SPLIT && __builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every lane of this wave has failed: nothing left to simulate
         if (SPLIT) { lane_alive = alive; if (wg_dead) break; }           // (SPLIT: the wave keeps pace with its producers' barriers until the workgroup votes to stop)
         double tg1 = 0.0, tg2 = 0.0, treal = 0.0;  // :635-637
@@ -569,11 +578,11 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         ++t_idx;
         if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], wr_bits);  // :851, :859, :934-935
     }
-    for (; year < (PHASE == 3 ? y_end : ry); ++year) {  // the whole wave failed early: pad (:902-916, :934-935)
+    for (; year < (kSliced ? y_end : ry); ++year) {  // the whole wave failed early: pad (:902-916, :934-935)
         put_sample(t_idx++, 0.0, infl);
         if (kTraj && valid && wrt) store_bits(&wrt[(int64_t)year * stride + (int64_t)li], kNanBits);
     }
-    if (PHASE == 3 && seg >= 0 && seg < io.seg_q - 1) {
+    if (kSliced && seg >= 0 && seg < io.seg_q - 1) {
         // not the block's last segment: hand the lanes' state over and raise the flag (every wave gets here: no early return above)
         *seg_at(0) = b1; *seg_at(1) = b2; *seg_at(2) = c1; *seg_at(3) = c2;
         if (ANNUAL) { *seg_at(4) = gacc1; *seg_at(5) = gacc2; }
@@ -647,7 +656,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
         }
     }
     __syncthreads();
-    uint64_t* ctr = io.out.counters ? io.out.counters + (PHASE == 2 ? (size_t)io.cand_out[blockIdx.y] * MCR_N_COUNTERS : 0) : nullptr;
+    uint64_t* ctr = io.out.counters ? io.out.counters + (kCand ? (size_t)io.cand_out[cand] * MCR_N_COUNTERS : 0) : nullptr;
     if (threadIdx.x == 0 && ctr) {
         atomicAdd((unsigned long long*)&ctr[MCR_CTR_SUCCESS], (unsigned long long)blk[0]);
         const uint64_t first = (uint64_t)path_block * kBlock;
@@ -1229,7 +1238,7 @@ static unsigned split_max_waves() {   // (read at every launch: tests compare bo
 // retirement years.  Resident slots = CUs x 6 workgroups (count-only) or x 5 (variants with per-path outputs); the slices are equal in COST
 // (an accumulation month is ~0.83 of a retirement month: no withdrawal).
 struct SegmentPlan { int n_split, n_full, q, max_polls, year[kMaxSegments + 1]; };
-static bool plan_segments(const DevParams& d, unsigned n_blocks, int mode, SegmentPlan* plan) {
+static bool plan_segments(const DevParams& d, unsigned n_blocks, int mode, SegmentPlan* plan, bool retirement_only = false) {
     int q = -1;     // (chosen below from the shape of the launch unless the environment says otherwise)
     if (const char* e = std::getenv("MCR_K1_SEGMENTS")) q = std::atoi(e);
     if (q >= 0 && q < 2) return false;
@@ -1254,7 +1263,7 @@ static bool plan_segments(const DevParams& d, unsigned n_blocks, int mode, Segme
     plan->q = q;
     plan->n_split = (int)slots;
     plan->n_full = (int)(n_blocks - slots);
-    const double acc = 0.83 * d.working_months, total = acc + (double)kMPY * d.retirement_years;
+    const double acc = retirement_only ? 0.0 : 0.83 * d.working_months, total = acc + (double)kMPY * d.retirement_years;   // (PHASE 4: the candidates resume at retirement)
     plan->year[0] = 0;
     for (int k = 1; k < q; ++k) {
         int y = (int)std::lround((total * k / q - acc) / kMPY);
@@ -1366,7 +1375,7 @@ static int launch_paths(const mcr_params* p, const mcr_rng* rng, uint32_t stream
             void* mem = nullptr;
             hipError_t e = hipMallocAsync(&mem, state_bytes + flag_bytes, stream);
             if (e == hipSuccess) {
-                io.snap = (double*)mem;
+                io.seg_state = (double*)mem;
                 io.seg_flags = (unsigned int*)((char*)mem + state_bytes);
                 io.seg_n_split = plan.n_split; io.seg_n_full = plan.n_full; io.seg_q = plan.q; io.seg_max_polls = plan.max_polls;
                 for (int k = 0; k <= plan.q; ++k) io.seg_year[k] = plan.year[k];
@@ -1525,11 +1534,33 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
         const bool split1 = (uint64_t)g1.x * (kBlock / 64) <= split_max_waves();
         const bool split2 = (uint64_t)g2.x * g2.y * (kBlock / 64) <= split_max_waves();
         const dim3 block2(2 * kBlock);
+        // the candidates' decumulations time-sliced (PHASE 4) where their workgroups are a few rounds of the resident slots
+        // with a mostly empty last one: the search's 17-month verification window at 50 000 paths is 3 332 workgroups = 2.17 rounds
+        SegmentPlan plan;
+        void* seg_mem = nullptr;
+        dim3 g4(0);
+        if (!split2 && plan_segments(top, g2.x * g2.y, 0, &plan, true)) {
+            const size_t state_bytes = (size_t)plan.n_split * (size_t)(9 + top.n_lock_slots) * kBlock * sizeof(double);
+            const size_t flag_bytes = (size_t)plan.n_split * (size_t)plan.q * sizeof(unsigned int);
+            if (hipMallocAsync(&seg_mem, state_bytes + flag_bytes, stream) == hipSuccess &&
+                hipMemsetAsync((char*)seg_mem + state_bytes, 0, flag_bytes, stream) == hipSuccess) {
+                io.seg_state = (double*)seg_mem;
+                io.seg_flags = (unsigned int*)((char*)seg_mem + state_bytes);
+                io.seg_n_split = plan.n_split; io.seg_n_full = plan.n_full; io.seg_q = plan.q; io.seg_max_polls = plan.max_polls;
+                io.seg_blocks_per_cand = (int32_t)g2.x;
+                for (int k = 0; k <= plan.q; ++k) io.seg_year[k] = plan.year[k];
+                g4 = dim3((unsigned)(plan.n_full + plan.q * plan.n_split));
+            } else {
+                (void)hipGetLastError();
+                if (seg_mem) { (void)hipFreeAsync(seg_mem, stream); seg_mem = nullptr; }
+            }
+        }
 #define MCR_PHASES(T, A)                                                                                          \
         do {                                                                                                       \
             if (split1) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 1, true>), g1, block2, lds, stream, top, io, d_blocks); \
             else hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 1>), g1, block, lds, stream, top, io, d_blocks);    \
             if (split2) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2, true>), g2, block2, lds, stream, top, io, d_blocks); \
+            else if (g4.x) hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 4>), g4, block, lds, stream, top, io, d_blocks);    \
             else hipLaunchKernelGGL((path_kernel<0, 0, T, A, false, 2>), g2, block, lds, stream, top, io, d_blocks);    \
         } while (0)
 #define MCR_PHASES_A(T) do { if (top.any_annual_tax) MCR_PHASES(T, true); else MCR_PHASES(T, false); } while (0)
@@ -1537,6 +1568,7 @@ static int probe_shared_prefix(const mcr_params* p, const mcr_rng* rng, uint32_t
 #undef MCR_PHASES_A
 #undef MCR_PHASES
         e = hipGetLastError();
+        if (seg_mem) (void)hipFreeAsync(seg_mem, stream);
     }
     const hipError_t ef = hipFreeAsync(mem, stream);
     if (e != hipSuccess) return hip_fail(e, "shared-prefix probe");

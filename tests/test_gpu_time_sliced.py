@@ -93,3 +93,34 @@ def test_sliced_launch_outputs_equal_the_plain_launch(want_trajectories):
             assert set(got) == set(plain)
             for k in plain:
                 assert np.array_equal(got[k], plain[k], equal_nan=True), (name, env, k)
+
+
+def test_sliced_probe_window_equals_plain_and_single_launches():
+    """The search's verification window (17 consecutive candidate months over 50 000 paths: 17 x 196 workgroups = 2.17 rounds of
+    the resident slots) resumes every candidate from its accumulation snapshot AND time-slices the decumulations (PHASE 4):
+    per-candidate counters equal the plain shared-prefix route, the all-recompute route and one launch per candidate."""
+    cfgd = [g for g in load_golden("paths_injected.json") if g["name"] == "C1_config_json_wm233"][0]["cfg"]
+    p = params_from_config(Config(**cfgd))
+    months = list(range(217, 234))
+    n = 50_000
+
+    def probes(env):
+        old = {k: os.environ.get(k) for k in KNOBS}
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            return E.probe_months(p, 4242, 0, 11, n, months).cpu().numpy()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+
+    plain = probes({"MCR_K1_SEGMENTS": "0"})
+    assert plain[:, 1].tolist() == [n] * len(months) and 0 < int(plain[0, 0]) <= int(plain[-1, 0]) <= n
+    for env in ({}, {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": "3"}, {"MCR_K1_SEGMENT_POLLS": "0"}):
+        assert np.array_equal(probes(env), plain), env
+    for m, row in zip(months[::4], plain[::4]):
+        one = E.run_batch_host(p, 4242, 0, 11, n, m, want_summary=False, want_trajectories=False)
+        assert row.tolist() == one["counters"].tolist(), m
