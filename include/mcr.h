@@ -224,7 +224,11 @@ int32_t mcr_stream_start_month_index(double current_age, int32_t working_months,
  * out: device pointers.  hip_stream: a hipStream_t (NULL = default stream).  The call is
  * asynchronous: it enqueues on hip_stream and returns.  device: HIP device ordinal.
  * (Count-only Philox launches of at most 3 072 path-wavefronts — 196 608 paths — run a latency-oriented form of the kernel,
- * two waves per 64 paths: same results, bit for bit.  MCR_K1_SPLIT_MAX_WAVES in the environment moves the limit, 0 = never.)
+ * two waves per 64 paths: same results, bit for bit.  MCR_K1_SPLIT_MAX_WAVES in the environment moves the limit, 0 = never.
+ * Philox launches of a few rounds of resident workgroups whose last round would be mostly empty — 10^6 paths are 2.54 rounds —
+ * run TIME-SLICED: some path blocks are cut into segments at retirement-year boundaries and dispatched so that the small
+ * work items come last; the hand-over state lives in a stream-ordered allocation of the call.  Same results, bit for bit;
+ * MCR_K1_SEGMENTS = segments per sliced block, 0 = never.)
  */
 int mcr_run_batch(const mcr_params* p, uint64_t seed, uint32_t stream_id,
                   uint64_t path_begin, uint64_t n_paths, int32_t working_months,
