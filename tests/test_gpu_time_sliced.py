@@ -124,3 +124,46 @@ def test_sliced_probe_window_equals_plain_and_single_launches():
     for m, row in zip(months[::4], plain[::4]):
         one = E.run_batch_host(p, 4242, 0, 11, n, m, want_summary=False, want_trajectories=False)
         assert row.tolist() == one["counters"].tolist(), m
+
+
+def test_sliced_launch_fuzz():
+    """Random scenarios (the reference-fixture fuzz set: zero allocations, annual taxes, frozen and indexed streams, odd working
+    months, terminal tax periods, 1-8 retirement years ...), random batch sizes just above the resident capacity, random segment
+    counts and output modes: sliced == plain in every output.  MCR_SLICE_FUZZ_ROUNDS / MCR_SLICE_FUZZ_SEED for soaks."""
+    rng = np.random.default_rng(int(os.environ.get("MCR_SLICE_FUZZ_SEED", "2026")))
+    groups = [g for g in load_golden("paths_fuzz.json") if len(g["cfg"]["other_income_streams"]) <= 16] + load_golden("paths_injected.json")
+    checked = 0
+    for _ in range(int(os.environ.get("MCR_SLICE_FUZZ_ROUNDS", "10"))):
+        g = groups[int(rng.integers(len(groups)))]
+        cfgd = dict(g["cfg"], retirement_years=int(rng.choice([g["cfg"]["retirement_years"], 4, 7, 12, 30])))
+        p = params_from_config(Config(**cfgd))
+        wm = int(rng.choice([g["working_months"], 0, 1, 11, 12, 13, int(rng.integers(0, 60))]))
+        mode = int(rng.integers(3))
+        slots = 256 * (6 if mode == 0 else 5)
+        n = int(rng.integers(slots * 256 + 1, slots * 256 * 2))
+        if mode == 2:
+            n = min(n, 360_000)                       # (host buffers of the trajectory outputs)
+        env = {"MCR_K1_SEGMENTS_ALWAYS": "1", "MCR_K1_SEGMENTS": str(int(rng.choice([2, 3, 4, 6, 8])))}
+        if rng.random() < 0.25:
+            env["MCR_K1_SEGMENT_POLLS"] = "0"
+        begin = int(rng.choice([0, 2**32 - 3, 2**40 + 17]))
+        kw = dict(want_summary=mode >= 1, want_trajectories=mode == 2)
+
+        def run(e):
+            old = {k: os.environ.get(k) for k in KNOBS}
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(e)
+            try:
+                return E.run_batch_host(p, 99, int(rng.integers(2)) * 0 + 1, begin, n, wm, **kw)
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None)
+                    if v is not None:
+                        os.environ[k] = v
+
+        plain, sliced = run({"MCR_K1_SEGMENTS": "0"}), run(env)
+        for k in plain:
+            assert np.array_equal(plain[k], sliced[k], equal_nan=True), (g["name"], wm, cfgd["retirement_years"], mode, n, env, k)
+        checked += 1
+    assert checked > 0
