@@ -175,8 +175,8 @@ __global__ __launch_bounds__(SPLIT ? 2 * kBlock : kBlock, SPLIT ? 4 : (MODE == 0
 #endif
     double* tab = tab_s;
     load_math_tables(tab, threadIdx.x, kThreads);
-    ZigTables zig{nullptr, nullptr, nullptr};
-    if (RNG == (int)MCR_RNG_NUMPY) zig = load_zig_tables(smem_raw, threadIdx.x, kThreads);
+    ZigTables zig{nullptr, nullptr, nullptr, nullptr};
+    if (RNG == (int)MCR_RNG_NUMPY) { zig = load_zig_tables(smem_raw, threadIdx.x, kThreads); zig.math_tab = tab; }
     // Philox stream: the gross factors of two months at a time, staged per lane (growth_rows2)
     double* stage = stage_s + (kStaged ? tid : 0);
     double* sum_col = sum_s + (kSumLds ? tid : 0);     // [0] first-year gross, [kBlock] first-year real gross, [2 kBlock] YearsToRuin bits
@@ -856,7 +856,10 @@ __global__ void shocks_kernel(uint64_t seed, uint32_t stream_id, uint64_t path_b
 // _draw_shock_path with the reference's NumPy stream: one thread per path, rows in order
 __global__ void np_shocks_kernel(const KernelIO io, int32_t n_months, double rho, double rho_c, double* out) {
     __shared__ __align__(16) unsigned char zraw[kZigLdsBytes];
-    const ZigTables zig = load_zig_tables(zraw, threadIdx.x, blockDim.x);
+    __shared__ double mtab[kTabDoubles];
+    load_math_tables(mtab, threadIdx.x, blockDim.x);
+    ZigTables zig = load_zig_tables(zraw, threadIdx.x, blockDim.x);
+    zig.math_tab = mtab;
     __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= io.n_paths) return;

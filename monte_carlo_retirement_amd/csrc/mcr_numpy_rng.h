@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mcr_math.h"
 #include "mcr_numpy_tables.h"
 
 namespace mcr {
@@ -23,6 +24,7 @@ struct ZigTables {  // LDS views
     const uint64_t* ki;
     const double* wi;
     const double* fi;
+    const double* math_tab;   // the workgroup's math tables (mcr_math.h): the wedge test's exp
 };
 
 __device__ __forceinline__ ZigTables load_zig_tables(unsigned char* lds, int tid, int nthreads) {
@@ -30,7 +32,7 @@ __device__ __forceinline__ ZigTables load_zig_tables(unsigned char* lds, int tid
     double* wi = reinterpret_cast<double*>(lds + kZigN * 8);
     double* fi = reinterpret_cast<double*>(lds + kZigN * 16);
     for (int i = tid; i < kZigN; i += nthreads) { ki[i] = kZigKi[i]; wi[i] = kZigWi[i]; fi[i] = kZigFi[i]; }
-    return ZigTables{ki, wi, fi};
+    return ZigTables{ki, wi, fi, nullptr};
 }
 
 // ---- SeedSequence -----------------------------------------------------------------------------
@@ -131,8 +133,11 @@ __device__ __forceinline__ double np_standard_normal(Pcg64& g, const ZigTables& 
                 const double yy = -log1p(-pcg64_next_double(g));
                 if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(kR + xx) : kR + xx;
             }
-        } else {  // wedge
-            if ((T.fi[idx - 1] - T.fi[idx]) * pcg64_next_double(g) + T.fi[idx] < exp(-0.5 * x * x)) return x;
+        } else {  // wedge.  exp(-x^2 / 2), |x| < 3.66, only decides accept / reject: the kernel's table exp (1.5 ulp) serves as
+                  // well as the device libm's (neither is glibc's bit for bit: a decision can differ where the two sides of the
+                  // test agree to ~1e-16, once in ~1e15 wedge draws) at a third of the instructions — and a wave takes this
+                  // branch whenever ANY of its 64 lanes does, i.e. for a third of all normals
+            if ((T.fi[idx - 1] - T.fi[idx]) * pcg64_next_double(g) + T.fi[idx] < fexp(-0.5 * x * x, T.math_tab, MathRegs::literals())) return x;
         }
     }
 }
