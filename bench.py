@@ -12,10 +12,11 @@ shard across ranks by GLOBAL path index (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: algorithmic fp64 ops / measured
 kernel time vs the fp64 vector-issue peak) and `cpu_baseline` (the CPU oracle timed on this box's
-host cores on a bounded sample of the same workload), plus one block per remaining BASELINE config:
-`accuracy_10k` (configs[0]'s 10k-path fixture), `hbm_kernels` (configs[2]), `s60` (configs[3]) and
+host cores on a bounded sample of the same workload: one thread, 16 threads and every usable core), plus one block per
+remaining BASELINE config: `accuracy_10k` (configs[0]'s 10k-path fixture), `hbm_kernels` / `hbm_kernels_rho0` (configs[2]:
+jorge.json with rho = 0.3 and as shipped), `class_api_1e7` (configs[2] through the drop-in class), `s60` (configs[3]),
 `search` (configs[4]: the whole bracket + bisection search at 50 000 paths per probe and the 10^6-path
-final run, through the drop-in class).  `config.ranks_seen` / `config.devices` say what the process
+final run, through the drop-in class) and `numpy_stream` (the literal-seed mode's rate).  `config.ranks_seen` / `config.devices` say what the process
 group actually contained.
 """
 
